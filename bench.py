@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""bench.py — stylised frames/s at 1024x1024 on N MI355X GPUs + roofline of the dominant kernel.
+
+A step = one stylised batch per rank: encode the rank's content frame(s) (RevResNet forward), cWCT
+against the cached style statistics, decode (RevResNet inverse) — BASELINE.json config 2 at N=1
+("single 1024x1024 frame, photorealistic RevResNet+cWCT, fp32 state").  Frames shard across ranks
+with no data-path collective (weak scaling: per-GPU work is fixed); torch.distributed (RCCL) is used
+only for the barrier and the max-over-ranks clock.  Inputs are resident in HBM before the timed region.
+
+    python bench.py [--gpus N --steps K --warmup W] [--size 1024] [--mode photo|art]
+                    [--frames-per-gpu 1] [--recompute-style] [--no-cpu-baseline]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--mode", default="photo", choices=["photo", "art"])
+    ap.add_argument("--frames-per-gpu", type=int, default=1)
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32"])
+    ap.add_argument("--recompute-style", action="store_true", help="re-encode + re-factor the style every frame "
+                    "(the reference's video loop, video_transfer.py:195) instead of caching it")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from models.RevResNet import RevResNet
+    from models.cWCT import cWCT
+    from vstnet_amd import _lib
+    from vstnet_amd.synth import synthetic_state_dict, synthetic_frames
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    S, fpg = args.size, args.frames_per_gpu
+    hd, sp = (16, 2) if args.mode == "photo" else (64, 1)
+    sd = synthetic_state_dict(1234, hd, sp)
+    net = RevResNet(hidden_dim=hd, sp_steps=sp, precision=args.precision)
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    cw = cWCT()
+
+    # frame f of the job has seed (0, f); rank r owns frames r*fpg .. r*fpg+fpg-1 (contiguous shard)
+    first = rank * fpg
+    import numpy as np
+    frames = []
+    for f in range(first, first + fpg):
+        rng = np.random.Generator(np.random.PCG64([0, f]))
+        frames.append(rng.random((3, S, S), dtype=np.float32))
+    content = torch.from_numpy(np.stack(frames)).to(dev)
+    style = synthetic_frames(1, S, S, seed=1).to(dev)
+
+    with torch.no_grad():
+        z_s = net(style)
+        s_stats = cw.style_stats(z_s)
+
+        def step():
+            z_c = net(content, forward=True)
+            if args.recompute_style:
+                zs = net(style, forward=True)
+                z_cs = cw.transfer(z_c, zs.expand(fpg, -1, -1, -1))
+            else:
+                z_cs = cw.transfer_with_stats(z_c, s_stats)
+            return net(z_cs, forward=False)
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+
+        for _ in range(args.warmup):
+            out = step()
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize(); barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        assert torch.isfinite(out).all()
+
+        # ---- live roofline of the dominant kernel: HIP events around each of its launches ------------
+        L = _lib.lib()
+        cin, cout = 256, 64                         # stage-3 / channel_reduction conv.1 (largest share of MFMA work)
+        _lib.check(L.vst_profile_begin(_lib.kernel_id(cin, cout, 1), 4096), "vst_profile_begin")
+        for _ in range(max(1, min(args.steps, 10))):
+            step()
+        tot_ms, n_launch = C.c_double(0), C.c_int(0)
+        _lib.check(L.vst_profile_end(C.byref(tot_ms), C.byref(n_launch)), "vst_profile_end")
+        avg_ms = tot_ms.value / max(1, n_launch.value)
+        px = fpg * (S // 4) * (S // 4)
+        alg_flops = 2.0 * 9 * cin * cout * px        # fp32-equivalent conv flops (the split executes 3x as bf16 MFMA)
+        achieved_tf = alg_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+
+    frames_total = world * fpg * args.steps
+    ms_per_step = elapsed / args.steps * 1e3
+    value = frames_total / elapsed
+    passes = 3 if args.recompute_style else 2
+    frame_bytes = (passes * 6540 + 384) * S * S + (128 * S * S if args.recompute_style else 0)
+    frame_gbs = frame_bytes * fpg * args.steps / elapsed / 1e9     # per GPU
+
+    rec = {
+        "metric": "stylized frames/sec at 1024x1024 (1/2/4/8 GPU) + % HBM roofline",
+        "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (bf16x3 split MFMA, f32 accumulate/state)" if args.precision == "bf16x3" else "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{'photorealistic' if args.mode == 'photo' else 'artistic'} {S}x{S} frame: RevResNet "
+                   f"forward + cWCT ({'style re-encoded per frame' if args.recompute_style else 'style statistics cached'})"
+                   " + RevResNet inverse", "frames_per_gpu": fpg, "sharding": f"{world} ranks x {fpg} frame(s), no collective",
+                   "weights": "synthetic seed 1234"},
+        "roofline": {"kernel": f"conv_mfma_kernel<{cin},{cout},1> (stage-3 conv.1)", "bound": "mfma",
+                     "achieved": round(achieved_tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved_tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                     "avg_launch_ms": round(avg_ms, 5), "launches_timed": n_launch.value,
+                     "note": "achieved counts algorithmic fp32 conv flops; the bf16x3 split issues 3x that on the MFMA pipe"},
+        "frame_hbm_roofline": {"bound": "hbm", "algorithmic_bytes_per_frame": frame_bytes,
+                               "achieved": round(frame_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(frame_gbs / HBM_PEAK_GBS, 4), "per": "GPU"},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        rec["cpu_baseline"] = cpu_baseline(sd, sp, S)
+    if rank == 0:
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sd, sp, S):
+    """The oracle (CPU restatement of the reference's torch-op sequence) timed on this host's cores on ONE
+    frame of the same workload (style code precomputed, like the GPU leg)."""
+    import torch
+    from oracle import cpu_ref
+    from vstnet_amd.synth import synthetic_frames
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    xc, xs = synthetic_frames(1, S, S, seed=0), synthetic_frames(1, S, S, seed=1)
+    with torch.no_grad():
+        small = synthetic_frames(1, 64, 64, seed=2)
+        cpu_ref.revnet_inverse(cpu_ref.revnet_forward(small, sd, sp), sd, sp)       # warm the thread pool
+        zs = cpu_ref.revnet_forward(xs, sd, sp)
+        t0 = time.perf_counter()
+        zc = cpu_ref.revnet_forward(xc, sd, sp)
+        zcs = cpu_ref.transfer(zc, zs)
+        cpu_ref.revnet_inverse(zcs, sd, sp)
+        dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 frame {S}x{S} (forward + cWCT + inverse, style code precomputed), oracle/cpu_ref.py on torch CPU ops",
+            "seconds": round(dt, 2)}
+
+
+if __name__ == "__main__":
+    main()

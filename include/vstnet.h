@@ -1,0 +1,144 @@
+/*
+ * vstnet.h — C ABI of libvstnet_hip.so: the MI355X (gfx950) implementation of CAP-VSTNet's
+ * inference hot path (RevResNet forward/inverse + cWCT).
+ *
+ * The reference (delldu/VSTNet) is pure Python on torch ops and defines no native interface for
+ * this path; its closest native analogue is ggml's
+ *     GGMLNetwork::engine_forward(int argc, TENSOR* argv[])   project/ggml/include/ggml_engine.h:610
+ * Each entry point below names the reference Python symbol (file:line, relative to the reference
+ * root) whose device work it replaces.  INTEGRATION.md shows the ctypes binding a maintainer of the
+ * reference would add in models/RevResNet.py / models/cWCT.py.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, <0 = VST_E_* (bad argument / unsupported shape),
+ *     >0 = a hipError_t raised by a launch.  No exceptions cross the ABI.
+ *   - all pointers are DEVICE pointers unless the name ends in _host; the library never allocates
+ *     device memory: outputs and workspaces are caller-provided (vst_*_workspace_bytes tell sizes).
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered and asynchronous.
+ *     Entry points are re-entrant; use one stream per host thread / per GPU.
+ *   - external tensors are NCHW fp32 contiguous (the reference's convention); H, W multiples of 4,
+ *     H, W >= 8 (SURVEY.md 8(b) "Tensor conventions").
+ *   - internal "state" buffers use the ZC layout described in DESIGN.md (quarter-resolution cells
+ *     of 256 channels-last floats); they are opaque to callers of the whole-pass entry points.
+ */
+#ifndef VSTNET_H
+#define VSTNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VST_OK 0
+#define VST_E_ARG (-1)      /* null pointer, non-positive size */
+#define VST_E_SHAPE (-2)    /* H/W not multiple of 4, < 8, unsupported channel count */
+#define VST_E_MODE (-3)     /* unknown precision / sp_steps / direction */
+#define VST_E_WORKSPACE (-4)
+
+/* conv arithmetic */
+#define VST_PREC_BF16X3 0   /* bf16 MFMA, hi/lo split operands (3 products), fp32 accumulate: ~3e-6 rel */
+#define VST_PREC_FP32 1     /* plain fp32 FMA direct convolution (diagnostic / cross-check, slow) */
+
+#define VST_NUM_BLOCKS 32   /* 30 stack blocks + 2 channel_reduction blocks */
+
+int vst_version(void);
+const char* vst_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weights.  A residual_block (models/RevResNet.py:68-94) has three 3x3 convs (conv.1, conv.4,
+ * conv.7).  vst_conv_packed_bytes/vst_pack_conv turn one OIHW fp32 weight tensor (device) into the
+ * packed form the kernels read: [fp32 taps-major copy | bf16 hi fragments | bf16 lo fragments].
+ * ------------------------------------------------------------------------------------------- */
+size_t vst_conv_packed_bytes(int cout, int cin);
+int vst_pack_conv(const float* w_oihw, int cout, int cin, void* packed, void* stream);
+
+typedef struct vst_conv_weights {
+    const void* packed;   /* from vst_pack_conv */
+    const float* bias;    /* [cout] fp32 */
+} vst_conv_weights;
+
+typedef struct vst_block_weights {
+    vst_conv_weights conv[3];
+} vst_block_weights;
+
+/* blocks[0..29] = stack.0..29, blocks[30..31] = channel_reduction.block_list.0..1 (host struct of
+ * device pointers; models/RevResNet.py:190,192-201) */
+typedef struct vst_net_weights {
+    vst_block_weights blocks[VST_NUM_BLOCKS];
+} vst_net_weights;
+
+/* ---------------------------------------------------------------------------------------------
+ * Layout glue (R-1..R-3 of SURVEY.md 8(a)): split/merge, injective_pad, squeeze/unsqueeze are
+ * address arithmetic in the ZC state layout; only the NCHW boundary needs data movement.
+ * state halves s1,s2: [B][H/4][W/4][256] fp32 each.
+ * ------------------------------------------------------------------------------------------- */
+/* x[B,C,H,W] (C<=16) -> s1 (channels C..15 zero), s2 = 0.   inj_pad.forward + split, RevResNet.py:212-214 */
+int vst_pack_input(const float* x, float* s1, float* s2, int B, int C, int H, int W, void* stream);
+/* s1 -> x[B,C,H,W]: merge + inj_pad.inverse, RevResNet.py:235-237 */
+int vst_unpack_output(const float* s1, float* x, int B, int C, int H, int W, void* stream);
+/* merge + "spread" (unsqueeze x sp_steps), RevResNet.py:139-144 -> z[B,32,H,W] (sp=2) or [B,128,H/2,W/2] (sp=1) */
+int vst_spread(const float* s1, const float* s2, float* z, int B, int H, int W, int sp_steps, void* stream);
+/* inverse of vst_spread: squeeze x sp_steps + split, RevResNet.py:148-154 */
+int vst_gather(const float* z, float* s1, float* s2, int B, int H, int W, int sp_steps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * One coupling block, in place on the state (R-4/R-5; residual_block.forward RevResNet.py:96-104,
+ * .inverse :106-116):   direction=+1:  dst += F(src)      direction=-1:  dst -= F(src)
+ * `channel` in {16,64,256}, `stride` in {1,2} (stride 2: src is read at the finer resolution).
+ * tmp must hold vst_block_tmp_bytes(B,H,W) bytes.
+ * ------------------------------------------------------------------------------------------- */
+size_t vst_block_tmp_bytes(int B, int H, int W);
+int vst_block_apply(const vst_block_weights* w, int channel, int stride, int direction, int precision,
+                    float* dst, const float* src, void* tmp, int B, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole passes (R-6/R-7): RevResNet._forward RevResNet.py:210-223 and ._inverse :225-239.
+ * workspace: vst_pass_workspace_bytes(B,H,W).
+ * ------------------------------------------------------------------------------------------- */
+size_t vst_pass_workspace_bytes(int B, int H, int W);
+int vst_revnet_forward(const vst_net_weights* w, const float* x, float* z, void* workspace,
+                       int B, int C_in, int H, int W, int sp_steps, int precision, void* stream);
+int vst_revnet_inverse(const vst_net_weights* w, const float* z, float* x, void* workspace,
+                       int B, int C_out, int H, int W, int sp_steps, int precision, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * cWCT (C-1..C-6; models/cWCT.py).  Feature matrices are x[N][L] fp32 row-major (one NCHW image:
+ * N channels, L = H*W).  `mask` (optional, may be NULL) is uint8[L]; with a mask only pixels whose
+ * label == `label` take part.
+ *
+ * vst_cwct_stats  : mean and covariance  C = Xc Xc^T/(n-1)  (cWCT.py:138-144,153-157), two-level
+ *                   shifted accumulation, final combine in fp64.  stats = double[1 + N + N*N]:
+ *                   {n, mean[N], cov[N*N]}.
+ * vst_cwct_factor : builds the affine map of one (content,style) pair from their stats:
+ *                   Lc = chol(Cc), Ls_i = chol(Cs_i) with the cumulative-jitter retry of
+ *                   cholesky_dec (cWCT.py:111-132), mixL = sum_i alpha_i Ls_i (+ alpha_c blend,
+ *                   cWCT.py:231-254), T = mixL * Lc^-1, t0 = mix_mean - T*mean_c.
+ *                   affine = float[N*N + N] {T, t0};  info = int[2 + n_styles] retry counts.
+ * vst_cwct_apply  : y[:,p] = T x[:,p] + t0  (cWCT.py:147,161-162 fused); with a mask only pixels
+ *                   whose label matches are written (in place allowed: y may alias x).
+ * ------------------------------------------------------------------------------------------- */
+size_t vst_cwct_stats_workspace_bytes(int N, long L);
+int vst_cwct_stats(const float* x, int N, long L, const uint8_t* mask, int label,
+                   double* stats, void* workspace, void* stream);
+int vst_cwct_factor(const double* content_stats, const double* const* style_stats_host_array,
+                    const float* alphas_host, int n_styles, float alpha_c, float eps, int N,
+                    float* affine, int* info, void* stream);
+int vst_cwct_apply(const float* x, float* y, int N, long L, const float* affine,
+                   const uint8_t* mask, int label, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Measurement hook (bench.py's live roofline figure): bracket every launch of one conv kernel class
+ * with HIP events on the launch stream.  Not thread-safe; one profiling session at a time.
+ *   vst_profile_begin(VST_KERNEL_ID(cin,cout,stride), max_records); ...run passes...;
+ *   vst_profile_end(&total_ms, &launches)   (synchronises on the recorded events)
+ * ------------------------------------------------------------------------------------------- */
+#define VST_KERNEL_ID(cin, cout, stride) (((cin) << 16) | ((cout) << 4) | (stride))
+int vst_profile_begin(int kernel_id, int max_records);
+int vst_profile_end(double* total_ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSTNET_H */

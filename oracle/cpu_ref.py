@@ -1,0 +1,284 @@
+"""ORACLE — test infrastructure, NOT product code.
+
+A from-scratch CPU (torch fp32 / fp64, ATen ops only) restatement of the
+reference's inference hot path: the RevResNet reversible encoder/decoder and the
+cWCT Cholesky whitening/colouring transform.  It is functional (no nn.Module):
+every function takes the plain ``state_dict`` of the reference
+(``stack.{i}.conv.{1,4,7}.{weight,bias}``, ...).
+
+Who may import this file: ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` — as the checker / the timed CPU baseline.
+The product path (``vstnet_amd``) never imports it and has no CPU fallback.
+
+Pinning: ``oracle/make_golden.py`` imports the real reference modules
+(/root/reference/models/{RevResNet,cWCT}.py, two shims) in
+the build container, checks this restatement against them and writes
+``tests/golden/*.npz``.  ``tests/test_oracle.py`` re-checks this file against
+those fixtures wherever it runs (the reference itself never travels).
+
+Every function cites the reference lines it follows (paths relative to
+/root/reference).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+STACK = [(1, 16)] * 10 + [(2, 64)] + [(1, 64)] * 9 + [(2, 256)] + [(1, 256)] * 9
+
+
+# --------------------------------------------------------------------------- R-1..R-3 glue
+def split(x):
+    """models/RevResNet.py:8-12 — channel halves."""
+    n = x.shape[1] // 2
+    return x[:, :n].contiguous(), x[:, n:].contiguous()
+
+
+def merge(x1, x2):
+    """models/RevResNet.py:15-16."""
+    return torch.cat((x1, x2), dim=1)
+
+
+def inj_pad_fwd(x, pad):
+    """models/RevResNet.py:25-28 — append `pad` zero channels."""
+    if pad == 0:
+        return x
+    z = x.new_zeros(x.shape[0], pad, x.shape[2], x.shape[3])
+    return torch.cat((x, z), dim=1)
+
+
+def inj_pad_inv(x, pad):
+    """models/RevResNet.py:30-31 — drop the last `pad` channels."""
+    return x[:, : x.shape[1] - pad]
+
+
+def squeeze(x):
+    """models/RevResNet.py:34-37 — out[b,(i*2+j)*D+d,h,w] = in[b,d,2h+i,2w+j]."""
+    b, d, h, w = x.shape
+    if h % 2 or w % 2:
+        raise RuntimeError("squeeze needs even H and W")
+    parts = [x[:, :, i::2, j::2] for i in (0, 1) for j in (0, 1)]
+    return torch.cat(parts, dim=1).contiguous()
+
+
+def unsqueeze(x):
+    """models/RevResNet.py:40-43 — exact inverse of squeeze."""
+    b, c, h, w = x.shape
+    d = c // 4
+    out = x.new_empty(b, d, 2 * h, 2 * w)
+    for i in (0, 1):
+        for j in (0, 1):
+            k = i * 2 + j
+            out[:, :, i::2, j::2] = x[:, k * d:(k + 1) * d]
+    return out
+
+
+# --------------------------------------------------------------------------- R-4 / R-5 block
+def _conv(x, w, b, stride=1):
+    # ReflectionPad2d(1) + Conv2d(k=3, padding=0, bias=True): models/RevResNet.py:79-88
+    return F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w, b, stride=stride)
+
+
+def residual_F(x2, sd, prefix, stride):
+    """F(x2) of models/RevResNet.py:79-88 (three reflect-padded 3x3 convs, ReLU between)."""
+    h = F.relu(_conv(x2, sd[prefix + "conv.1.weight"], sd[prefix + "conv.1.bias"], stride))
+    h = F.relu(_conv(h, sd[prefix + "conv.4.weight"], sd[prefix + "conv.4.bias"]))
+    return _conv(h, sd[prefix + "conv.7.weight"], sd[prefix + "conv.7.bias"])
+
+
+def block_forward(x1, x2, sd, prefix, stride):
+    """models/RevResNet.py:96-104 — (x1,x2) -> (x2', F(x2)+x1')."""
+    fx2 = residual_F(x2, sd, prefix, stride)
+    if stride == 2:
+        x1, x2 = squeeze(x1), squeeze(x2)
+    return x2, fx2 + x1
+
+
+def block_inverse(x2, y1, sd, prefix, stride):
+    """models/RevResNet.py:106-116 — (x2', y1) -> (x1, x2)."""
+    if stride == 2:
+        x2 = unsqueeze(x2)
+    x1 = y1 - residual_F(x2, sd, prefix, stride)
+    if stride == 2:
+        x1 = unsqueeze(x1)
+    return x1, x2
+
+
+# --------------------------------------------------------------------------- R-6 / R-7 network
+def revnet_forward(x, sd, sp_steps=2):
+    """models/RevResNet.py:210-223 + channel_reduction.forward :131-146."""
+    x = inj_pad_fwd(x, 32 - x.shape[1])
+    x1, x2 = split(x)
+    for i, (stride, _) in enumerate(STACK):
+        x1, x2 = block_forward(x1, x2, sd, f"stack.{i}.", stride)
+    x1, x2 = split(merge(x1, x2))               # channel_reduction.forward: split, inj_pad(0)
+    for i in range(2):
+        x1, x2 = block_forward(x1, x2, sd, f"channel_reduction.block_list.{i}.", 1)
+    z = merge(x1, x2)
+    for _ in range(sp_steps):                   # "spread" :141-144 == unsqueeze
+        z = unsqueeze(z)
+    return z
+
+
+def revnet_inverse(z, sd, sp_steps=2, in_channel=3):
+    """models/RevResNet.py:225-239 + channel_reduction.inverse :148-163."""
+    for _ in range(sp_steps):
+        z = squeeze(z)
+    a, b = split(z)
+    for i in (1, 0):
+        a, b = block_inverse(a, b, sd, f"channel_reduction.block_list.{i}.", 1)
+    a, b = split(merge(a, b))
+    for i in range(len(STACK) - 1, -1, -1):
+        a, b = block_inverse(a, b, sd, f"stack.{i}.", STACK[i][0])
+    return inj_pad_inv(merge(a, b), 32 - in_channel)
+
+
+# --------------------------------------------------------------------------- C-4 Cholesky
+def cholesky_dec(conv, eps=2e-5, invert=False, return_tries=False):
+    """models/cWCT.py:111-132 — Cholesky with the cumulative jitter schedule
+    (after k failed retries the total added jitter is eps*k(k+1)/2), optional general inverse."""
+    tries = 0
+    L, info = torch.linalg.cholesky_ex(conv)
+    if int(info.max()) != 0:
+        iden = torch.eye(conv.shape[-1], dtype=conv.dtype)
+        e = eps
+        while True:
+            conv = conv + iden * e
+            tries += 1
+            L, info = torch.linalg.cholesky_ex(conv)
+            if int(info.max()) == 0:
+                break
+            e = e + eps
+    if invert:
+        L = torch.inverse(L)
+    return (L, tries) if return_tries else L
+
+
+# --------------------------------------------------------------------------- C-2 / C-3
+def whitening(x, eps=2e-5):
+    """models/cWCT.py:134-149 on a 2-D [N,L] matrix."""
+    xc = x - x.mean(-1, keepdim=True)
+    conv = (xc @ xc.transpose(-1, -2)) / (x.shape[-1] - 1)
+    return cholesky_dec(conv, eps, invert=True) @ xc
+
+
+def coloring(whiten, style, eps=2e-5):
+    """models/cWCT.py:152-164."""
+    mu = style.mean(-1, keepdim=True)
+    sc = style - mu
+    conv = (sc @ sc.transpose(-1, -2)) / (style.shape[-1] - 1)
+    return cholesky_dec(conv, eps, invert=False) @ whiten + mu
+
+
+def transfer(content, style, eps=2e-5, use_double=False):
+    """C-1: the INTENDED no-mask semantics of models/cWCT.py:24-47 — per-sample
+    coloring(whitening(c_b), s_b).  (The fork's batched `whitening` raises on 3-D input,
+    SURVEY.md 8(a) C-1; per-sample 2-D calls are what upstream computes and are bit-identical to
+    interpolation(c,[s],[1.0],0.0).)"""
+    B, N, H, W = content.shape
+    dt = content.dtype
+    c = content.reshape(B, N, -1)
+    s = style.reshape(B, N, -1)
+    if use_double:
+        c, s = c.double(), s.double()
+    out = torch.stack([coloring(whitening(c[b], eps), s[b], eps) for b in range(B)])
+    return out.to(dt).reshape(B, N, H, W)
+
+
+# --------------------------------------------------------------------------- C-5 masked
+def compute_label_info(cseg, sseg):
+    """models/cWCT.py:166-189 — labels of the content mask and their validity
+    (count_c>10, count_s>10, ratio<100 both ways)."""
+    cseg = np.asarray(cseg)
+    sseg = np.asarray(sseg)
+    label_set = np.unique(cseg)
+    indicator = np.zeros(int(cseg.max()) + 1)
+    for l in label_set:
+        a = int((cseg == l).sum())
+        b = int((sseg == l).sum())
+        indicator[l] = a > 10 and b > 10 and a / b < 100 and b / a < 100
+    return label_set, indicator
+
+
+def transfer_seg(content, style, cmask, smask, eps=2e-5, use_double=False):
+    """models/cWCT.py:49-109 — per label: gather columns, whiten, colour, scatter back.
+    Masks are used at feature resolution (not resized in this fork, :72-73)."""
+    B, N, H, W = content.shape
+    dt = content.dtype
+    c = content.reshape(B, N, -1).clone()
+    s = style.reshape(B, N, -1)
+    if use_double:
+        c, s = c.double(), s.double()
+    for b in range(B):
+        labels, ok = compute_label_info(cmask[b], smask[b])
+        cm = torch.from_numpy(np.asarray(cmask[b]).reshape(-1).astype(np.int64))
+        sm = torch.from_numpy(np.asarray(smask[b]).reshape(-1).astype(np.int64))
+        src = c[b]
+        tgt = src.clone()
+        for l in labels:
+            if not ok[l]:
+                continue
+            ci = torch.nonzero(cm == int(l)).reshape(-1)
+            si = torch.nonzero(sm == int(l)).reshape(-1)
+            if ci.numel() == 0 or si.numel() == 0:
+                continue
+            tgt[:, ci] = coloring(whitening(src[:, ci], eps), s[b][:, si], eps)
+        c[b] = tgt
+    return c.to(dt).reshape(B, N, H, W)
+
+
+# --------------------------------------------------------------------------- C-6 interpolation
+def interpolation(content, styles, alphas, alpha_c=0.0, eps=2e-5, use_double=False):
+    """models/cWCT.py:206-262 — whiten content once, mix the styles' Cholesky factors and means,
+    optionally blend with the content's own factor/mean."""
+    assert len(styles) == len(alphas)
+    B, N, H, W = content.shape
+    dt = content.dtype
+    c = content.reshape(B, N, -1)
+    if use_double:
+        c = c.double()
+    cmean = c.mean(-1)
+    cc = c - cmean.unsqueeze(-1)
+    out = torch.empty_like(cc)
+    for b in range(B):
+        conv = (cc[b] @ cc[b].t()) / (cc.shape[-1] - 1)
+        invLc = cholesky_dec(conv, eps, invert=True)
+        whiten = invLc @ cc[b]
+        mixL = torch.zeros_like(invLc)
+        mixm = torch.zeros_like(cmean[b])
+        for sf, a in zip(styles, alphas):
+            assert sf.shape[0] == B and sf.shape[1] == N
+            s = sf.reshape(B, N, -1)[b]
+            if use_double:
+                s = s.double()
+            sm = s.mean(-1)
+            sc = s - sm.unsqueeze(-1)
+            sconv = (sc @ sc.t()) / (s.shape[-1] - 1)
+            mixL = mixL + cholesky_dec(sconv, eps) * a
+            mixm = mixm + sm * a
+        if alpha_c != 0.0:
+            Lc = cholesky_dec(conv, eps)
+            mixL = mixL * (1 - alpha_c) + Lc * alpha_c
+            mixm = mixm * (1 - alpha_c) + cmean[b] * alpha_c
+        out[b] = mixL @ whiten + mixm.unsqueeze(-1)
+    return out.to(dt).reshape(B, N, H, W)
+
+
+# --------------------------------------------------------------------------- whole stylisation (H-1)
+def stylize(content, style, sd, sp_steps=2, cmask=None, smask=None, alpha_c=None):
+    """image_transfer.py:172-201 — fwd, fwd, transfer|interpolation, inv."""
+    zc = revnet_forward(content, sd, sp_steps)
+    zs = revnet_forward(style, sd, sp_steps)
+    if alpha_c is not None and cmask is None and smask is None:
+        zcs = interpolation(zc, [zs], [1.0], alpha_c)
+    elif cmask is None or smask is None:
+        zcs = transfer(zc, zs)
+    else:
+        zcs = transfer_seg(zc, zs, cmask, smask)
+    return zc, zs, zcs, revnet_inverse(zcs, sd, sp_steps)
+
+
+def to_uint8(img):
+    """image_transfer.py:217-218 — mul(255).clamp(0,255).byte() (truncation), NCHW -> NHWC."""
+    return img.mul(255).clamp(0, 255).byte().permute(0, 2, 3, 1).contiguous()

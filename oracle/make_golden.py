@@ -1,0 +1,257 @@
+"""ORACLE tooling — mint golden fixtures from the real reference (build container only).
+
+Imports /root/reference/models/{RevResNet,cWCT}.py on CPU with the two shims recorded in
+SURVEY.md 8(c) (a stub ``todos`` module, a no-op ``pdb.set_trace``), loads this repo's synthetic
+state_dict into the reference network, and
+
+  1. checks ``oracle/cpu_ref.py`` (our restatement) against the reference on every case, and
+  2. writes the reference's outputs as small ``.npz`` fixtures under ``tests/golden/``.
+
+Only data (inputs / expected outputs) is written; no reference source travels.
+Run:  python oracle/make_golden.py          (needs /root/reference; never runs on the GPU box)
+"""
+from __future__ import annotations
+
+import io
+import contextlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("VST_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+
+from oracle import cpu_ref  # noqa: E402
+from vstnet_amd.synth import synthetic_state_dict, synthetic_frames, synthetic_mask  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+SEED_W = 1234
+
+
+def import_reference():
+    """Import the two hot-path modules of the reference with the SURVEY 8(c) shims."""
+    import pdb
+    pdb.set_trace = lambda *a, **k: None
+    todos = types.ModuleType("todos")
+    todos.debug = types.SimpleNamespace(output_var=lambda *a, **k: None)
+    sys.modules["todos"] = todos
+    sys.path.insert(0, REF)
+    with contextlib.redirect_stdout(io.StringIO()):
+        import models.RevResNet as ref_rev
+        import models.cWCT as ref_cwct
+    sys.path.remove(REF)
+    return ref_rev, ref_cwct
+
+
+def build_ref_net(ref_rev, mode):
+    hd, sp = (16, 2) if mode == "photo" else (64, 1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ref_rev.RevResNet(hidden_dim=hd, sp_steps=sp)
+    sd = synthetic_state_dict(SEED_W, hd, sp)
+    net.load_state_dict(sd)
+    net.eval()
+    return net, sd, sp
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    rng = np.random.Generator(np.random.PCG64([seed, 4242]))
+    return torch.from_numpy(rng.uniform(lo, hi, size=shape).astype(np.float32))
+
+
+def check(name, ours, ref, tol=2e-5):
+    ours, ref = ours.double(), ref.double()
+    err = float((ours - ref).abs().max())
+    scale = float(ref.abs().max()) + 1e-30
+    status = "ok" if err <= tol * max(1.0, scale) else "MISMATCH"
+    print(f"  [{status}] {name:44s} max|d|={err:.3e}  max|ref|={scale:.3e}")
+    if status != "ok":
+        raise SystemExit(f"oracle restatement disagrees with the reference on {name}")
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        out[k] = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {os.path.relpath(path, REPO)} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def sd_checksum(sd):
+    return float(sum(float(v.double().sum()) for v in sd.values()))
+
+
+@torch.no_grad()
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    ref_rev, ref_cwct = import_reference()
+
+    # ------------------------------------------------------------------ glue (R-2, R-3)
+    print("glue")
+    x = torch.arange(2 * 3 * 4 * 6, dtype=torch.float32).reshape(2, 3, 4, 6)
+    sq = ref_rev.squeeze(x)
+    check("squeeze", cpu_ref.squeeze(x), sq, 0)
+    check("unsqueeze", cpu_ref.unsqueeze(sq), ref_rev.unsqueeze(sq), 0)
+    pad = ref_rev.injective_pad(5)
+    padded = pad.forward(x).contiguous()
+    check("inj_pad.forward", cpu_ref.inj_pad_fwd(x, 5), padded, 0)
+    check("inj_pad.inverse", cpu_ref.inj_pad_inv(padded, 5), pad.inverse(padded), 0)
+    save("glue", x=x, squeeze=sq, unsqueeze_of_squeeze=ref_rev.unsqueeze(sq), inj_pad5=padded)
+
+    # ------------------------------------------------------------------ blocks (R-4, R-5)
+    print("blocks")
+    net, sd, _ = build_ref_net(ref_rev, "photo")
+    blk = {}
+    # (name, module, prefix, stride, x1 shape, x2 shape)
+    cases = [
+        ("c16s1", net.stack[3], "stack.3.", 1, (1, 16, 12, 16)),
+        ("c64s2", net.stack[10], "stack.10.", 2, (1, 16, 16, 24)),
+        ("c64s1", net.stack[13], "stack.13.", 1, (1, 64, 8, 12)),
+        ("c256s2", net.stack[20], "stack.20.", 2, (1, 64, 16, 8)),
+        ("c256s1", net.stack[25], "stack.25.", 1, (1, 256, 8, 8)),
+        ("cr0", net.channel_reduction.block_list[0], "channel_reduction.block_list.0.", 1, (2, 256, 4, 8)),
+    ]
+    for i, (nm, mod, prefix, stride, shp) in enumerate(cases):
+        x1, x2 = rnd(shp, 10 + i), rnd(shp, 20 + i)
+        o_x2, o_y1 = mod.forward((x1.clone(), x2.clone()))
+        c_x2, c_y1 = cpu_ref.block_forward(x1, x2, sd, prefix, stride)
+        check(f"{nm}.forward.x2", c_x2, o_x2, 0)
+        check(f"{nm}.forward.y1", c_y1, o_y1)
+        r_x1, r_x2 = mod.inverse((o_x2.clone(), o_y1.clone()))
+        i_x1, i_x2 = cpu_ref.block_inverse(o_x2, o_y1, sd, prefix, stride)
+        check(f"{nm}.inverse.x1", i_x1, r_x1)
+        check(f"{nm}.inverse.x2", i_x2, r_x2, 0)
+        blk.update({f"{nm}_x1": x1, f"{nm}_x2": x2, f"{nm}_out_x2": o_x2, f"{nm}_out_y1": o_y1,
+                    f"{nm}_inv_x1": r_x1, f"{nm}_inv_x2": r_x2})
+    save("blocks", weights_seed=SEED_W, weights_checksum=sd_checksum(sd), **blk)
+
+    # ------------------------------------------------------------------ whole network (R-6, R-7)
+    print("network")
+    for mode in ("photo", "art"):
+        net, sd, sp = build_ref_net(ref_rev, mode)
+        g = {}
+        for tag, (b, h, w) in {"16": (1, 16, 16), "24x40": (1, 24, 40), "32b2": (2, 32, 32)}.items():
+            x = synthetic_frames(b, h, w, seed=5)
+            z = net(x, forward=True)
+            check(f"{mode}.{tag}.forward", cpu_ref.revnet_forward(x, sd, sp), z)
+            zp = z + 0.05 * rnd(tuple(z.shape), 33)       # a perturbed code, like z_cs
+            y = net(zp, forward=False)
+            check(f"{mode}.{tag}.inverse", cpu_ref.revnet_inverse(zp, sd, sp), y)
+            rec = net(z, forward=False)
+            check(f"{mode}.{tag}.roundtrip", rec, x, 5e-6)
+            g.update({f"x_{tag}": x, f"z_{tag}": z, f"zp_{tag}": zp, f"y_{tag}": y})
+        save(f"net_{mode}", weights_seed=SEED_W, weights_checksum=sd_checksum(sd), frames_seed=5, **g)
+
+    # ------------------------------------------------------------------ cWCT (C-1 .. C-6)
+    print("cwct")
+    cw = ref_cwct.cWCT()
+    g = {}
+    for N, L, Ls in ((32, 50, 64), (32, 4096, 3000), (128, 1024, 777)):
+        c = rnd((N, L), 100 + N + L, -1, 1) * torch.linspace(0.2, 2.0, N).unsqueeze(1) + 0.3
+        s = rnd((N, Ls), 200 + N + L, -1, 1) * torch.linspace(1.5, 0.1, N).unsqueeze(1) - 0.1
+        # give the channels some correlation so the factors are not diagonal
+        mixc = torch.eye(N) + 0.3 * rnd((N, N), 300 + N)
+        mixs = torch.eye(N) + 0.3 * rnd((N, N), 400 + N)
+        c, s = mixc @ c, mixs @ s
+        wh = cw.whitening(c)
+        co = cw.coloring(wh, s)
+        check(f"whitening N={N} L={L}", cpu_ref.whitening(c), wh, 2e-4)
+        check(f"coloring  N={N} L={L}", cpu_ref.coloring(wh, s), co, 2e-5)
+        g.update({f"c_{N}_{L}": c, f"s_{N}_{L}": s, f"whiten_{N}_{L}": wh, f"color_{N}_{L}": co})
+    save("cwct_2d", **g)
+
+    g = {}
+    c4 = torch.stack([rnd((32, 12, 20), 500 + b) * (1 + b) + 0.1 * b for b in range(2)])
+    s4 = torch.stack([rnd((32, 16, 12), 600 + b) * 0.5 - 0.2 * b for b in range(2)])
+    # C-1: the fork's batched path raises; record that and the intended per-sample result
+    raised = False
+    try:
+        cw.transfer(c4, s4)
+    except RuntimeError:
+        raised = True
+    print(f"  reference cWCT.transfer (no mask, 4-D input) raises RuntimeError: {raised}")
+    per_sample = torch.stack([cw.coloring(cw.whitening(c4[b].reshape(32, -1)), s4[b].reshape(32, -1))
+                              for b in range(2)]).reshape(c4.shape)
+    interp0 = cw.interpolation(c4, [s4], [1.0], 0.0)
+    check("transfer per-sample == interpolation(alpha_c=0)", per_sample, interp0, 2e-5)
+    check("cpu_ref.transfer", cpu_ref.transfer(c4, s4), per_sample, 2e-5)
+    s4b = torch.stack([rnd((32, 8, 24), 700 + b) * 0.8 + 0.3 for b in range(2)])
+    for ac in (0.0, 0.3):
+        o = cw.interpolation(c4, [s4, s4b], [0.6, 0.4], ac)
+        check(f"interpolation 2 styles alpha_c={ac}", cpu_ref.interpolation(c4, [s4, s4b], [0.6, 0.4], ac), o, 2e-5)
+        g[f"interp2_ac{ac}"] = o
+    o1 = cw.interpolation(c4, [s4], [1.0], 0.3)
+    check("interpolation 1 style alpha_c=0.3", cpu_ref.interpolation(c4, [s4], [1.0], 0.3), o1, 2e-5)
+    save("cwct_transfer", c=c4, s=s4, s_b=s4b, transfer=per_sample, interp1_ac0=interp0, interp1_ac03=o1,
+         fork_transfer_raises=raised, **g)
+
+    # C-5 masked: labels 0..3 valid, label 4 = 6-px speck (invalid), label 9 only in content
+    # (missing from style -> count_s == 0 -> invalid), label 7 only in style (ignored).
+    H, W = 24, 40
+    cm = synthetic_mask(H, W, labels=4, seed=1)
+    cm[20:24, 30:40] = 9
+    sm = synthetic_mask(20, 36, labels=4, seed=2, speck=False)
+    sm[0:3, 0:12] = 7
+    cmask, smask = cm[None], sm[None]
+    cf = rnd((1, 32, H, W), 800) + 0.2
+    sf = rnd((1, 32, 20, 36), 801) * 0.7 - 0.1
+    labels, ok = cw.compute_label_info(cmask[0], smask[0])
+    l2, ok2 = cpu_ref.compute_label_info(cmask[0], smask[0])
+    assert list(labels) == list(l2) and np.array_equal(ok, ok2), (labels, ok, l2, ok2)
+    print(f"  labels {labels.tolist()} valid {ok.astype(int).tolist()}")
+    om = cw.transfer(cf.clone(), sf.clone(), cmask, smask)
+    check("transfer_seg", cpu_ref.transfer_seg(cf, sf, cmask, smask), om, 5e-5)
+    save("cwct_masked", c=cf, s=sf, cmask=cmask, smask=smask, out=om, labels=labels, valid=ok)
+
+    # C-4 jitter branch: covariance of L<N samples is rank deficient -> Cholesky fails -> retries
+    N, L = 32, 12
+    xr = rnd((N, L), 900)
+    xc = xr - xr.mean(-1, keepdim=True)
+    conv = (xc @ xc.t()) / (L - 1)
+    Lr = cw.cholesky_dec(conv.clone(), invert=False)
+    Lo, tries = cpu_ref.cholesky_dec(conv.clone(), return_tries=True)
+    resid = float((Lr @ Lr.t() - conv).abs().max())
+    print(f"  rank-deficient Cholesky: oracle retries={tries}, |LLt-C|max={resid:.3e}")
+    check("cholesky_dec jitter", Lo, Lr, 1e-3)
+    # exactly singular, exactly representable matrix: deterministic first-try failure
+    sing = torch.ones(4, 4)
+    Ls_ref = cw.cholesky_dec(sing.clone())
+    Ls_o, t2 = cpu_ref.cholesky_dec(sing.clone(), return_tries=True)
+    check("cholesky_dec ones(4,4)", Ls_o, Ls_ref, 1e-4)
+    # a matrix needing several retries: diag(1,-3e-5) + jitter 2e-5*k(k+1)/2 > 3e-5 at k=2
+    neg = torch.diag(torch.tensor([1.0, -3e-5]))
+    Ln_ref = cw.cholesky_dec(neg.clone())
+    Ln_o, t3 = cpu_ref.cholesky_dec(neg.clone(), return_tries=True)
+    check("cholesky_dec diag(1,-3e-5)", Ln_o, Ln_ref, 1e-5)
+    print(f"  retries: ones(4,4)={t2}  diag(1,-3e-5)={t3}")
+    save("cwct_jitter", conv=conv, L=Lr, tries=tries, ones4_L=Ls_ref, ones4_tries=t2,
+         neg_in=neg, neg_L=Ln_ref, neg_tries=t3)
+
+    # ------------------------------------------------------------------ config 1: photo 256x256 stylisation
+    print("config-1 (photo 256x256, image_transfer.py call sequence)")
+    net, sd, sp = build_ref_net(ref_rev, "photo")
+    xc_ = synthetic_frames(1, 256, 256, seed=0)
+    xs_ = synthetic_frames(1, 256, 256, seed=1)
+    zc = net(xc_, forward=True)
+    zs = net(xs_, forward=True)
+    zcs = cw.interpolation(zc, [zs], [1.0], 0.0)      # == intended transfer (C-1)
+    sty = net(zcs, forward=False)
+    o_zc, o_zs, o_zcs, o_sty = cpu_ref.stylize(xc_, xs_, sd, sp)
+    check("config1 z_c", o_zc, zc)
+    check("config1 z_cs", o_zcs, zcs, 5e-5)
+    check("config1 stylized", o_sty, sty, 5e-5)
+    u8 = sty.mul(255).clamp(0, 255).byte().permute(0, 2, 3, 1).contiguous()
+    stats = lambda t: np.array([float(t.min()), float(t.max()), float(t.double().mean()), float(t.double().std())])
+    save("config1_photo256", content_seed=0, style_seed=1, weights_seed=SEED_W,
+         zc_stats=stats(zc), zs_stats=stats(zs), zcs_stats=stats(zcs),
+         zc_sub=zc[:, :, ::8, ::8], zcs_sub=zcs[:, :, ::8, ::8], stylized=sty, stylized_u8=u8)
+    print("all oracle checks passed")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,324 @@
+"""GPU parity tests: the HIP path (through the C ABI of libvstnet_hip.so) against the oracle
+(oracle/cpu_ref.py) and the golden vectors minted from the reference.
+
+Tolerance (BASELINE.json north_star): outputs within 1e-3 relative (fp32) of the reference, checked
+both as rel-L2 and as max|d|/max|ref|.  The bf16x3 split-precision convs land near 3e-6, so the
+asserts below use tighter budgets where the case allows, to catch regressions early.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref
+from vstnet_amd import _lib
+from vstnet_amd.synth import synthetic_state_dict, synthetic_frames, synthetic_mask
+from tests.zc import nchw_to_zc, zc_to_nchw, ptr, stream, rel_err
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+TOL = 1e-3            # the north_star budget
+TIGHT = 5e-5          # what the bf16x3 path is expected to hold on these weights
+
+
+@pytest.fixture(scope="module")
+def L():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _lib.lib()
+
+
+def make_net(mode="photo", precision="bf16x3", seed=1234):
+    from models.RevResNet import RevResNet
+    hd, sp = (16, 2) if mode == "photo" else (64, 1)
+    net = RevResNet(hidden_dim=hd, sp_steps=sp, precision=precision)
+    sd = synthetic_state_dict(seed, hd, sp)
+    net.load_state_dict(sd)
+    return net.to("cuda").eval(), sd, sp
+
+
+def assert_close(got, ref, tol, what):
+    l2, mx = rel_err(got, ref)
+    assert l2 <= tol and mx <= tol, f"{what}: rel-L2 {l2:.3e}, max-rel {mx:.3e} (tol {tol:g})"
+    return l2, mx
+
+
+# ------------------------------------------------------------------------------------------- glue
+@pytest.mark.parametrize("shape", [(1, 3, 8, 8), (2, 3, 24, 40), (1, 3, 64, 68), (1, 5, 16, 132)])
+def test_pack_unpack_input(L, shape):
+    B, Cc, H, W = shape
+    x = torch.rand(shape, device="cuda")
+    s1 = torch.full((B, H // 4, W // 4, 256), 7.0, device="cuda")
+    s2 = torch.full_like(s1, 7.0)
+    _lib.check(L.vst_pack_input(ptr(x), ptr(s1), ptr(s2), B, Cc, H, W, stream()), "pack")
+    ref = cpu_ref.inj_pad_fwd(x.cpu(), 32 - Cc)
+    assert torch.equal(zc_to_nchw(s1.cpu(), 16), ref[:, :16])
+    assert torch.equal(zc_to_nchw(s2.cpu(), 16), ref[:, 16:])
+    y = torch.empty_like(x)
+    _lib.check(L.vst_unpack_output(ptr(s1), ptr(y), B, Cc, H, W, stream()), "unpack")
+    assert torch.equal(y, x)
+
+
+@pytest.mark.parametrize("sp", [1, 2])
+@pytest.mark.parametrize("shape", [(1, 8, 8), (2, 24, 40), (1, 64, 72), (1, 16, 264)])
+def test_spread_gather(L, sp, shape):
+    B, H, W = shape
+    s1 = torch.randn(B, H // 4, W // 4, 256, device="cuda")
+    s2 = torch.randn_like(s1)
+    zshape = (B, 32, H, W) if sp == 2 else (B, 128, H // 2, W // 2)
+    z = torch.full(zshape, -9.0, device="cuda")
+    _lib.check(L.vst_spread(ptr(s1), ptr(s2), ptr(z), B, H, W, sp, stream()), "spread")
+    m = cpu_ref.merge(zc_to_nchw(s1.cpu(), 256), zc_to_nchw(s2.cpu(), 256))
+    ref = m
+    for _ in range(sp):
+        ref = cpu_ref.unsqueeze(ref)
+    assert torch.equal(z.cpu(), ref)
+    g1, g2 = torch.zeros_like(s1), torch.zeros_like(s2)
+    _lib.check(L.vst_gather(ptr(z), ptr(g1), ptr(g2), B, H, W, sp, stream()), "gather")
+    assert torch.equal(g1, s1) and torch.equal(g2, s2)
+
+
+# ------------------------------------------------------------------------------------------- blocks
+BLOCKS = [("c16s1", 3, 16, 1), ("c64s2", 10, 64, 2), ("c64s1", 13, 64, 1), ("c256s2", 20, 256, 2),
+          ("c256s1", 25, 256, 1), ("cr0", 30, 256, 1)]
+
+
+def run_block(L, net, k, channel, stride, direction, precision, dst_nchw, src_nchw, H, W):
+    """dst/src: NCHW views at their own levels -> returns updated dst view (same level as given)."""
+    B = dst_nchw.shape[0]
+    dst = nchw_to_zc(dst_nchw).cuda()
+    src = nchw_to_zc(src_nchw).cuda()
+    tmp = torch.empty(L.vst_block_tmp_bytes(B, H, W), dtype=torch.uint8, device="cuda")
+    w = net._ensure_packed(torch.device("cuda", torch.cuda.current_device()))
+    rc = L.vst_block_apply(C.byref(w.blocks[k]), channel, stride, direction, precision, ptr(dst), ptr(src), ptr(tmp),
+                           B, H, W, stream())
+    _lib.check(rc, "vst_block_apply")
+    return zc_to_nchw(dst.cpu(), dst_nchw.shape[1])
+
+
+@pytest.mark.parametrize("precision,tol", [(_lib.PREC_FP32, 2e-6), (_lib.PREC_BF16X3, 2e-5)])
+@pytest.mark.parametrize("name,k,channel,stride", BLOCKS)
+def test_block_golden(L, golden, name, k, channel, stride, precision, tol):
+    g = golden("blocks")
+    net, sd, _ = make_net("photo")
+    x1, x2 = T(g[f"{name}_x1"]), T(g[f"{name}_x2"])
+    lv = {16: 0, 64: 1, 256: 2}[channel]
+    H, W = x1.shape[2] << (lv - (stride == 2)), x1.shape[3] << (lv - (stride == 2))
+    # forward: y1 = F(x2) + squeeze?(x1); dst holds x1 (finer view for stride 2 — same memory)
+    y1 = run_block(L, net, k, channel, stride, +1, precision, x1, x2, H, W)
+    ref_y1 = T(g[f"{name}_out_y1"])
+    if stride == 2:
+        y1 = cpu_ref.squeeze(y1)
+    assert_close(y1, ref_y1, tol, f"{name} forward y1")
+    # inverse: x1 = y1 - F(x2)
+    src = T(g[f"{name}_out_x2"])
+    if stride == 2:
+        src = cpu_ref.unsqueeze(src)
+    x1r = run_block(L, net, k, channel, stride, -1, precision, ref_y1, src, H, W)
+    ref_x1 = T(g[f"{name}_inv_x1"])
+    if stride == 2:
+        x1r = cpu_ref.unsqueeze(x1r)
+    assert_close(x1r, ref_x1, tol, f"{name} inverse x1")
+
+
+# ------------------------------------------------------------------------------------------- network
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["photo", "art"])
+def test_network_golden(golden, mode, precision):
+    g = golden(f"net_{mode}")
+    net, sd, sp = make_net(mode, precision)
+    tol = 5e-6 if precision == "fp32" else TIGHT
+    for tag in ("16", "24x40", "32b2"):
+        x = T(g[f"x_{tag}"]).cuda()
+        z = net(x, forward=True)
+        assert z.shape == T(g[f"z_{tag}"]).shape
+        assert_close(z, T(g[f"z_{tag}"]), tol, f"{mode}.{tag} forward")
+        y = net(T(g[f"zp_{tag}"]).cuda(), forward=False)
+        assert_close(y, T(g[f"y_{tag}"]), tol, f"{mode}.{tag} inverse")
+        rec = net(z, forward=False)
+        assert_close(rec, x, 5e-6, f"{mode}.{tag} inverse(forward(x))")
+
+
+@pytest.mark.parametrize("mode,shape", [("photo", (1, 72, 104)), ("photo", (2, 64, 64)), ("art", (1, 40, 136)),
+                                        ("photo", (1, 8, 8)), ("art", (3, 8, 12))])
+def test_network_vs_oracle_ragged(mode, shape):
+    """tile-edge / tiny / batched shapes against the oracle on the same seeded inputs"""
+    net, sd, sp = make_net(mode)
+    B, H, W = shape
+    x = synthetic_frames(B, H, W, seed=11)
+    with torch.no_grad():
+        zr = cpu_ref.revnet_forward(x, sd, sp)
+    z = net(x.cuda())
+    assert_close(z, zr, TIGHT, f"{mode} {shape} forward")
+    zp = zr + 0.03 * torch.randn_like(zr)
+    with torch.no_grad():
+        yr = cpu_ref.revnet_inverse(zp, sd, sp)
+    assert_close(net(zp.cuda(), forward=False), yr, TIGHT, f"{mode} {shape} inverse")
+
+
+def test_bad_shapes_raise():
+    net, _, _ = make_net("photo")
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 30, 30, device="cuda"))
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 4, 4, device="cuda"))
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 4, 16, 16, device="cuda"))
+
+
+def test_batch_independence():
+    net, _, _ = make_net("art")
+    x = synthetic_frames(3, 32, 48, seed=3).cuda()
+    zb = net(x)
+    for b in range(3):
+        assert torch.equal(zb[b:b + 1], net(x[b:b + 1]))
+
+
+# ------------------------------------------------------------------------------------------- cWCT
+def test_cwct_2d_golden(golden):
+    from models.cWCT import cWCT
+    g = golden("cwct_2d")
+    cw = cWCT()
+    for N, Lp, tol in ((32, 4096, 2e-4), (128, 1024, 2e-4), (32, 50, 5e-2)):
+        c, s = T(g[f"c_{N}_{Lp}"]).cuda(), T(g[f"s_{N}_{Lp}"]).cuda()
+        assert_close(cw.whitening(c), T(g[f"whiten_{N}_{Lp}"]), tol, f"whitening {N}x{Lp}")
+        assert_close(cw.coloring(T(g[f"whiten_{N}_{Lp}"]).cuda(), s), T(g[f"color_{N}_{Lp}"]), 2e-5, f"coloring {N}x{Lp}")
+
+
+def test_cwct_stats_fp64(L):
+    """mean/cov against an fp64 two-pass computation, large offset to stress cancellation"""
+    from models.cWCT import cWCT
+    cw = cWCT()
+    for N, Lp in ((32, 100003), (128, 5000), (16, 777), (64, 64)):
+        x = (torch.randn(N, Lp, dtype=torch.float64) * torch.linspace(0.01, 3, N, dtype=torch.float64)[:, None] + 50.0)
+        st = cw.stats(x.float().cuda()).cpu()
+        xd = x.float().double()
+        mu = xd.mean(-1)
+        cov = (xd - mu[:, None]) @ (xd - mu[:, None]).t() / (Lp - 1)
+        assert st[0] == Lp
+        assert float((st[1:1 + N] - mu).abs().max()) < 1e-5
+        err = float((st[1 + N:].reshape(N, N) - cov).abs().max() / cov.abs().max())
+        assert err < 2e-6, (N, Lp, err)
+
+
+def test_cwct_transfer_golden(golden):
+    from models.cWCT import cWCT
+    g = golden("cwct_transfer")
+    cw = cWCT()
+    c, s, sb = T(g["c"]).cuda(), T(g["s"]).cuda(), T(g["s_b"]).cuda()
+    assert_close(cw.transfer(c, s), T(g["transfer"]), 2e-5, "transfer")
+    assert_close(cw.interpolation(c, [s], [1.0], 0.3), T(g["interp1_ac03"]), 2e-5, "interp ac=.3")
+    assert_close(cw.interpolation(c, [s, sb], [0.6, 0.4], 0.0), T(g["interp2_ac0.0"]), 2e-5, "interp2 ac=0")
+    assert_close(cw.interpolation(c, [s, sb], [0.6, 0.4], 0.3), T(g["interp2_ac0.3"]), 2e-5, "interp2 ac=.3")
+
+
+def test_cwct_masked_golden(golden):
+    from models.cWCT import cWCT
+    g = golden("cwct_masked")
+    cw = cWCT()
+    c = T(g["c"]).cuda()
+    out = cw.transfer(c, T(g["s"]).cuda(), g["cmask"], g["smask"])
+    assert_close(out, T(g["out"]), 5e-5, "transfer_seg")
+    keep = T(np.isin(g["cmask"][0], [4, 9]))
+    assert torch.equal(out[0][:, keep].cpu(), T(g["c"])[0][:, keep])
+    assert torch.equal(c.cpu(), T(g["c"]))          # input not mutated
+
+
+def test_cwct_jitter_golden(golden):
+    from models.cWCT import cWCT
+    g = golden("cwct_jitter")
+    cw = cWCT()
+    # deterministic failures: ones(4,4) is exactly singular; diag(1,-3e-5) needs two retries.  Embed them
+    # in 16x16 identity blocks (the HIP path supports N in {16,32,64,128}).
+    def embed(m):
+        e = torch.eye(16)
+        e[:m.shape[0], :m.shape[1]] = m
+        return e
+    L1 = cw.cholesky_dec(embed(T(g["neg_in"])).cuda())
+    assert int(cw.last_info[2]) == int(g["neg_tries"]) == 2
+    assert_close(L1[:2, :2], T(g["neg_L"]), 1e-5, "chol diag(1,-3e-5)")
+    L2 = cw.cholesky_dec(embed(torch.ones(4, 4)).cuda())
+    assert int(cw.last_info[2]) == int(g["ones4_tries"]) == 1
+    assert_close(L2[:4, :4], T(g["ones4_L"]), 1e-3, "chol ones(4,4)")
+    # rank-deficient covariance (12 samples, 32 channels): same number of retries as the reference,
+    # factor within the conditioning of the jittered matrix
+    L3 = cw.cholesky_dec(T(g["conv"]).cuda())
+    assert int(cw.last_info[2]) == int(g["tries"])
+    assert_close(L3 @ L3.t(), T(g["L"]) @ T(g["L"]).t(), 1e-4, "jittered L L^T")
+
+
+def test_cwct_mask_errors():
+    from models.cWCT import cWCT
+    cw = cWCT()
+    c = torch.rand(1, 32, 8, 8, device="cuda")
+    with pytest.raises(ValueError):
+        cw.transfer(c, c, np.zeros((1, 4, 4), np.uint8), np.zeros((1, 8, 8), np.uint8))
+
+
+# ------------------------------------------------------------------------------------------- whole stylisation
+def test_config1_golden(golden):
+    """BASELINE config 1: photorealistic 256x256, image_transfer.py call sequence."""
+    from models.cWCT import cWCT
+    g = golden("config1_photo256")
+    net, sd, sp = make_net("photo")
+    cw = cWCT()
+    xc = synthetic_frames(1, 256, 256, seed=int(g["content_seed"])).cuda()
+    xs = synthetic_frames(1, 256, 256, seed=int(g["style_seed"])).cuda()
+    zc, zs = net(xc, forward=True), net(xs, forward=True)
+    zcs = cw.transfer(zc, zs)
+    sty = net(zcs, forward=False)
+    assert_close(zc[:, :, ::8, ::8], T(g["zc_sub"]), TIGHT, "z_c")
+    assert_close(zcs[:, :, ::8, ::8], T(g["zcs_sub"]), 2e-4, "z_cs")
+    l2, mx = assert_close(sty, T(g["stylized"]), 2e-4, "stylized")
+    u8 = cpu_ref.to_uint8(sty.cpu())
+    d = (u8.int() - T(g["stylized_u8"]).int()).abs()
+    assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 5e-3
+    stats = lambda t: np.array([float(t.min()), float(t.max()), float(t.double().mean()), float(t.double().std())])
+    assert np.allclose(stats(zc), g["zc_stats"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(stats(zcs), g["zcs_stats"], rtol=1e-3, atol=1e-4)
+
+
+def test_masked_stylisation_vs_oracle():
+    """config-5 style call (per-region cWCT) at a size the oracle finishes in seconds"""
+    from models.cWCT import cWCT
+    net, sd, sp = make_net("photo")
+    cw = cWCT()
+    H, W = 72, 128
+    xc, xs = synthetic_frames(1, H, W, seed=21), synthetic_frames(1, 64, 96, seed=22)
+    cm, sm = synthetic_mask(H, W, 5, seed=3)[None], synthetic_mask(64, 96, 5, seed=4, speck=False)[None]
+    with torch.no_grad():
+        zc, zs, zcs, sty = cpu_ref.stylize(xc, xs, sd, sp, cm, sm)
+    g_zc, g_zs = net(xc.cuda()), net(xs.cuda())
+    g_zcs = cw.transfer(g_zc, g_zs, cm, sm)
+    assert_close(g_zcs, zcs, 2e-4, "masked z_cs")
+    assert_close(net(g_zcs, forward=False), sty, 2e-4, "masked stylized")
+
+
+# ------------------------------------------------------------------------------------------- full size properties
+def test_full_size_properties_1024():
+    """BASELINE config 2 size (photo 1024x1024): size-independent properties instead of the oracle."""
+    from models.cWCT import cWCT
+    net, sd, sp = make_net("photo")
+    cw = cWCT()
+    xc = synthetic_frames(1, 1024, 1024, seed=0).cuda()
+    xs = synthetic_frames(1, 1024, 1024, seed=1).cuda()
+    zc, zs = net(xc), net(xs)
+    assert torch.isfinite(zc).all()
+    # 1. invertibility: inverse(forward(x)) == x  (the reference holds ~3e-7)
+    rec = net(zc, forward=False)
+    assert float((rec - xc).abs().max()) < 5e-6
+    # 2. cWCT: the transferred code has the style's mean and covariance
+    zcs = cw.transfer(zc, zs)
+    a = zcs[0].reshape(32, -1).double()
+    b = zs[0].reshape(32, -1).double()
+    cov = lambda m: (m - m.mean(-1, keepdim=True)) @ (m - m.mean(-1, keepdim=True)).t() / (m.shape[1] - 1)
+    assert float((a.mean(-1) - b.mean(-1)).abs().max()) < 1e-5
+    assert float((cov(a) - cov(b)).abs().max() / cov(b).abs().max()) < 1e-4
+    # 3. agreement with the exact-fp32 diagnostic path on a crop-independent statistic
+    net32, _, _ = make_net("photo", "fp32")
+    z32 = net32(xc[:, :, :128, :128].contiguous())
+    zc_crop = net(xc[:, :, :128, :128].contiguous())
+    assert_close(zc_crop, z32, TIGHT, "bf16x3 vs fp32 path")
+    # 4. stylised frame is finite and decodes
+    sty = net(zcs, forward=False)
+    assert torch.isfinite(sty).all() and sty.shape == xc.shape

@@ -1,0 +1,108 @@
+"""CPU: host logic — the C-ABI library loads and exports everything include/vstnet.h declares, the
+drop-in classes keep the reference's state_dict / attribute contract, argument errors are loud, and
+there is no CPU fallback.  No compute call is made (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import vstnet_amd
+from vstnet_amd import _lib
+from vstnet_amd.synth import synthetic_state_dict, state_dict_spec
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.lib()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(REPO, "include", "vstnet.h")).read()
+    declared = set(re.findall(r"\b(vst_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"vst_conv_weights", "vst_block_weights", "vst_net_weights"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_sizes_and_errors_without_gpu(lib):
+    assert lib.vst_version() >= 100
+    assert lib.vst_pass_workspace_bytes(1, 1024, 1024) == 1024 * 1024 * 160
+    assert lib.vst_block_tmp_bytes(2, 64, 32) == 2 * 64 * 32 * 32
+    # packed conv = fp32 taps-major + 2 x bf16 fragment sections
+    assert lib.vst_conv_packed_bytes(64, 256) == 9 * 256 * 64 * 4 + 2 * (72 * 4 * 64 * 16)
+    assert lib.vst_conv_packed_bytes(4, 16) == ((9 * 16 * 4 * 4 + 255) // 256 * 256) + 2 * (5 * 4 * 16 * 16)
+    assert lib.vst_cwct_stats_workspace_bytes(32, 1 << 20) == 512 * (32 * 32 + 64 + 4) * 4
+    # argument validation happens before any launch
+    null = C.c_void_p(0)
+    one = C.c_void_p(1)
+    assert lib.vst_pack_input(null, one, one, 1, 3, 16, 16, null) == -1
+    assert lib.vst_pack_input(one, one, one, 1, 3, 18, 16, null) == -2
+    assert lib.vst_pack_input(one, one, one, 1, 3, 4, 16, null) == -2
+    assert lib.vst_spread(one, one, one, 1, 16, 16, 3, null) == -3
+    assert lib.vst_cwct_apply(one, one, 48, 100, one, null, 0, null) == -2
+    assert lib.vst_cwct_stats(one, 32, 100, null, 0, one, null, null) == -4
+    net = _lib.NetWeights()
+    assert lib.vst_revnet_forward(C.byref(net), one, one, null, 1, 3, 16, 16, 2, 0, null) == -4
+    assert lib.vst_revnet_forward(C.byref(net), one, one, one, 1, 3, 16, 16, 5, 0, null) == -3
+    assert b"multiples of 4" in lib.vst_error_string(-2)
+
+
+def test_state_dict_contract():
+    from models.RevResNet import RevResNet     # the reference's import path
+    for hd, sp in ((16, 2), (64, 1)):
+        net = RevResNet(hidden_dim=hd, sp_steps=sp)
+        sd = net.state_dict()
+        spec = state_dict_spec(hd, sp)
+        assert list(sd.keys()) == [k for k, _ in spec] and len(sd) == 192
+        assert all(tuple(sd[k].shape) == tuple(s) for k, s in spec)
+        assert sum(p.numel() for p in net.parameters()) == 4089936
+        assert int(net.down_scale) == 4
+        net.load_state_dict(synthetic_state_dict(1234, hd, sp))     # strict
+        assert all(float(v.abs().sum()) > 0 for k, v in net.state_dict().items() if k.endswith("bias"))
+    with pytest.raises(NotImplementedError):
+        RevResNet(hidden_dim=32, sp_steps=2)
+    with pytest.raises(NotImplementedError):
+        RevResNet(nBlocks=[4, 4, 4])
+
+
+def test_no_cpu_fallback():
+    from models.RevResNet import RevResNet
+    from models.cWCT import cWCT
+    net = RevResNet()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(1, 3, 16, 16))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(1, 32, 16, 16), forward=False)
+    cw = cWCT()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cw.transfer(torch.zeros(1, 32, 8, 8), torch.zeros(1, 32, 8, 8))
+    with pytest.raises(AssertionError):
+        cw.interpolation(torch.zeros(1, 32, 8, 8), [torch.zeros(1, 32, 8, 8)], [0.5, 0.5])
+
+
+def test_product_does_not_import_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, "vstnet_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), f
+    for f in ("models/RevResNet.py", "models/cWCT.py"):
+        assert "oracle" not in open(os.path.join(REPO, f)).read()
+
+
+def test_compute_label_info_matches_oracle(golden):
+    from oracle import cpu_ref
+    from models.cWCT import cWCT
+    g = golden("cwct_masked")
+    labels, ok = cWCT().compute_label_info(g["cmask"][0], g["smask"][0])
+    l2, ok2 = cpu_ref.compute_label_info(g["cmask"][0], g["smask"][0])
+    assert list(labels) == list(l2) == list(g["labels"])
+    assert np.array_equal(ok, ok2) and np.array_equal(ok, g["valid"])

@@ -1,0 +1,126 @@
+"""CPU: the oracle restatement (oracle/cpu_ref.py) against the golden vectors minted from the real
+reference by oracle/make_golden.py.  Runs anywhere (no GPU, no /root/reference)."""
+import numpy as np
+import torch
+
+from oracle import cpu_ref
+from vstnet_amd.synth import synthetic_state_dict, synthetic_frames
+
+T = torch.from_numpy
+
+
+def close(a, b, tol=2e-5):
+    a, b = a.double(), b.double()
+    assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+
+
+def test_glue(golden):
+    g = golden("glue")
+    x = T(g["x"])
+    assert torch.equal(cpu_ref.squeeze(x), T(g["squeeze"]))
+    assert torch.equal(cpu_ref.unsqueeze(T(g["squeeze"])), T(g["unsqueeze_of_squeeze"]))
+    assert torch.equal(cpu_ref.unsqueeze(cpu_ref.squeeze(x)), x)
+    assert torch.equal(cpu_ref.inj_pad_fwd(x, 5), T(g["inj_pad5"]))
+    assert torch.equal(cpu_ref.inj_pad_inv(T(g["inj_pad5"]), 5), x)
+
+
+BLOCKS = [("c16s1", "stack.3.", 1), ("c64s2", "stack.10.", 2), ("c64s1", "stack.13.", 1),
+          ("c256s2", "stack.20.", 2), ("c256s1", "stack.25.", 1), ("cr0", "channel_reduction.block_list.0.", 1)]
+
+
+def test_weights_are_the_fixture_weights(golden):
+    g = golden("blocks")
+    sd = synthetic_state_dict(int(g["weights_seed"]))
+    assert abs(sum(float(v.double().sum()) for v in sd.values()) - float(g["weights_checksum"])) < 1e-9
+    assert len(sd) == 192 and sum(v.numel() for v in sd.values()) == 4089936
+
+
+def test_blocks(golden):
+    g = golden("blocks")
+    sd = synthetic_state_dict(int(g["weights_seed"]))
+    for nm, prefix, stride in BLOCKS:
+        x1, x2 = T(g[f"{nm}_x1"]), T(g[f"{nm}_x2"])
+        o2, y1 = cpu_ref.block_forward(x1, x2, sd, prefix, stride)
+        close(o2, T(g[f"{nm}_out_x2"]), 0)
+        close(y1, T(g[f"{nm}_out_y1"]))
+        i1, i2 = cpu_ref.block_inverse(T(g[f"{nm}_out_x2"]), T(g[f"{nm}_out_y1"]), sd, prefix, stride)
+        close(i1, T(g[f"{nm}_inv_x1"]))
+        close(i2, T(g[f"{nm}_inv_x2"]), 0)
+
+
+def test_network(golden):
+    for mode, hd, sp in (("photo", 16, 2), ("art", 64, 1)):
+        g = golden(f"net_{mode}")
+        sd = synthetic_state_dict(int(g["weights_seed"]), hd, sp)
+        for tag in ("16", "24x40", "32b2"):
+            x = T(g[f"x_{tag}"])
+            b, _, h, w = x.shape
+            assert torch.equal(x, synthetic_frames(b, h, w, seed=int(g["frames_seed"])))
+            with torch.no_grad():
+                close(cpu_ref.revnet_forward(x, sd, sp), T(g[f"z_{tag}"]))
+                close(cpu_ref.revnet_inverse(T(g[f"zp_{tag}"]), sd, sp), T(g[f"y_{tag}"]))
+                close(cpu_ref.revnet_inverse(T(g[f"z_{tag}"]), sd, sp), x, 5e-6)
+
+
+def test_cwct_2d(golden):
+    g = golden("cwct_2d")
+    for N, L in ((32, 50), (32, 4096), (128, 1024)):
+        c, s = T(g[f"c_{N}_{L}"]), T(g[f"s_{N}_{L}"])
+        wh = cpu_ref.whitening(c)
+        close(wh, T(g[f"whiten_{N}_{L}"]), 2e-4)
+        close(cpu_ref.coloring(T(g[f"whiten_{N}_{L}"]), s), T(g[f"color_{N}_{L}"]))
+        # property: whitened features have identity covariance; coloured ones the style's covariance
+        cov = lambda m: (m - m.mean(-1, keepdim=True)) @ (m - m.mean(-1, keepdim=True)).t() / (m.shape[1] - 1)
+        if L >= 8 * N:       # well-conditioned cases only (L=50 has cond ~1e6)
+            assert float((cov(wh.double()) - torch.eye(N)).abs().max()) < 2e-2
+            out = T(g[f"color_{N}_{L}"]).double()
+            assert float((cov(out) - cov(s.double())).abs().max()) < 2e-2 * float(cov(s.double()).abs().max())
+
+
+def test_cwct_transfer_and_interpolation(golden):
+    g = golden("cwct_transfer")
+    c, s, sb = T(g["c"]), T(g["s"]), T(g["s_b"])
+    assert bool(g["fork_transfer_raises"])          # documents SURVEY 8(a) C-1
+    close(cpu_ref.transfer(c, s), T(g["transfer"]))
+    close(cpu_ref.interpolation(c, [s], [1.0], 0.0), T(g["interp1_ac0"]))
+    close(cpu_ref.interpolation(c, [s], [1.0], 0.3), T(g["interp1_ac03"]))
+    close(cpu_ref.interpolation(c, [s, sb], [0.6, 0.4], 0.0), T(g["interp2_ac0.0"]))
+    close(cpu_ref.interpolation(c, [s, sb], [0.6, 0.4], 0.3), T(g["interp2_ac0.3"]))
+
+
+def test_cwct_masked(golden):
+    g = golden("cwct_masked")
+    labels, ok = cpu_ref.compute_label_info(g["cmask"][0], g["smask"][0])
+    assert list(labels) == list(g["labels"]) and np.array_equal(ok, g["valid"])
+    out = cpu_ref.transfer_seg(T(g["c"]), T(g["s"]), g["cmask"], g["smask"])
+    close(out, T(g["out"]), 5e-5)
+    # invalid labels (speck, label missing from style) keep the content feature
+    keep = np.isin(g["cmask"][0], [4, 9])
+    assert torch.equal(out[0][:, T(keep)], T(g["c"])[0][:, T(keep)])
+
+
+def test_cholesky_jitter(golden):
+    g = golden("cwct_jitter")
+    L, tries = cpu_ref.cholesky_dec(T(g["conv"]), return_tries=True)
+    assert tries == int(g["tries"]) >= 1
+    close(L, T(g["L"]), 1e-3)
+    L1, t1 = cpu_ref.cholesky_dec(torch.ones(4, 4), return_tries=True)
+    assert t1 == int(g["ones4_tries"]) == 1
+    close(L1, T(g["ones4_L"]), 1e-4)
+    L2, t2 = cpu_ref.cholesky_dec(T(g["neg_in"]), return_tries=True)
+    assert t2 == int(g["neg_tries"]) == 2          # cumulative schedule: 2e-5, then +4e-5
+    close(L2, T(g["neg_L"]), 1e-5)
+
+
+def test_config1(golden):
+    g = golden("config1_photo256")
+    sd = synthetic_state_dict(int(g["weights_seed"]))
+    xc = synthetic_frames(1, 256, 256, seed=int(g["content_seed"]))
+    xs = synthetic_frames(1, 256, 256, seed=int(g["style_seed"]))
+    with torch.no_grad():
+        zc, zs, zcs, sty = cpu_ref.stylize(xc, xs, sd, 2)
+    close(zc[:, :, ::8, ::8], T(g["zc_sub"]))
+    close(zcs[:, :, ::8, ::8], T(g["zcs_sub"]), 5e-5)
+    close(sty, T(g["stylized"]), 5e-5)
+    diff = (cpu_ref.to_uint8(sty).int() - T(g["stylized_u8"]).int()).abs()
+    assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 1e-3

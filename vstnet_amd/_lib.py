@@ -1,0 +1,113 @@
+"""ctypes binding of libvstnet_hip.so (C ABI declared in include/vstnet.h) and its in-tree build.
+
+There is deliberately no fallback: if the shared library is missing or a call returns a non-zero
+status, a ``VstError`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import glob
+import os
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_DIR = os.path.dirname(PKG_DIR)
+LIB_PATH = os.path.join(PKG_DIR, "libvstnet_hip.so")
+SOURCES = sorted(glob.glob(os.path.join(PKG_DIR, "csrc", "*.hip")))
+HEADERS = sorted(glob.glob(os.path.join(PKG_DIR, "csrc", "*.h"))) + [os.path.join(REPO_DIR, "include", "vstnet.h")]
+
+NUM_BLOCKS = 32
+PREC_BF16X3 = 0
+PREC_FP32 = 1
+
+# every symbol include/vstnet.h declares
+EXPORTS = [
+    "vst_version", "vst_error_string", "vst_conv_packed_bytes", "vst_pack_conv", "vst_pack_input",
+    "vst_unpack_output", "vst_spread", "vst_gather", "vst_block_tmp_bytes", "vst_block_apply",
+    "vst_pass_workspace_bytes", "vst_revnet_forward", "vst_revnet_inverse",
+    "vst_cwct_stats_workspace_bytes", "vst_cwct_stats", "vst_cwct_factor", "vst_cwct_apply",
+    "vst_profile_begin", "vst_profile_end",
+]
+
+
+class VstError(RuntimeError):
+    pass
+
+
+class ConvWeights(C.Structure):
+    _fields_ = [("packed", C.c_void_p), ("bias", C.c_void_p)]
+
+
+class BlockWeights(C.Structure):
+    _fields_ = [("conv", ConvWeights * 3)]
+
+
+class NetWeights(C.Structure):
+    _fields_ = [("blocks", BlockWeights * NUM_BLOCKS)]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into vstnet_amd/libvstnet_hip.so (cross-compiles without a GPU)."""
+    newest_src = max(os.path.getmtime(p) for p in SOURCES + HEADERS)
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest_src:
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
+           "-I", os.path.join(REPO_DIR, "include"), "-o", LIB_PATH] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the library (never builds implicitly on a box without hipcc; raises if absent)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VstError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback for the HIP path)")
+    L = C.CDLL(LIB_PATH)
+    vp, i, f, sz, lg = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long
+    sig = {
+        "vst_version": (i, []),
+        "vst_error_string": (C.c_char_p, [i]),
+        "vst_conv_packed_bytes": (sz, [i, i]),
+        "vst_pack_conv": (i, [vp, i, i, vp, vp]),
+        "vst_pack_input": (i, [vp, vp, vp, i, i, i, i, vp]),
+        "vst_unpack_output": (i, [vp, vp, i, i, i, i, vp]),
+        "vst_spread": (i, [vp, vp, vp, i, i, i, i, vp]),
+        "vst_gather": (i, [vp, vp, vp, i, i, i, i, vp]),
+        "vst_block_tmp_bytes": (sz, [i, i, i]),
+        "vst_block_apply": (i, [C.POINTER(BlockWeights), i, i, i, i, vp, vp, vp, i, i, i, vp]),
+        "vst_pass_workspace_bytes": (sz, [i, i, i]),
+        "vst_revnet_forward": (i, [C.POINTER(NetWeights), vp, vp, vp, i, i, i, i, i, i, vp]),
+        "vst_revnet_inverse": (i, [C.POINTER(NetWeights), vp, vp, vp, i, i, i, i, i, i, vp]),
+        "vst_cwct_stats_workspace_bytes": (sz, [i, lg]),
+        "vst_cwct_stats": (i, [vp, i, lg, vp, i, vp, vp, vp]),
+        "vst_cwct_factor": (i, [vp, C.POINTER(vp), C.POINTER(f), i, f, f, i, vp, vp, vp]),
+        "vst_cwct_apply": (i, [vp, vp, i, lg, vp, vp, i, vp]),
+        "vst_profile_begin": (i, [i, i]),
+        "vst_profile_end": (i, [C.POINTER(C.c_double), C.POINTER(i)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def kernel_id(cin: int, cout: int, stride: int) -> int:
+    """VST_KERNEL_ID of include/vstnet.h."""
+    return (cin << 16) | (cout << 4) | stride
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().vst_error_string(rc).decode()
+        raise VstError(f"{what} failed with status {rc}: {msg}")

@@ -1,0 +1,66 @@
+// Shared device/host helpers for libvstnet_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "vstnet.h"
+
+#define VST_RETURN_IF_LAUNCH_FAILED()                      \
+    do {                                                   \
+        hipError_t e__ = hipGetLastError();                \
+        if (e__ != hipSuccess) return (int)e__;            \
+    } while (0)
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---------------------------------------------------------------------------------------------
+// ZC state layout.  One half of the reversible state of an HxW image is [H/4][W/4][256] floats.
+// A "view level" l in {0,1,2} sees it as an (H>>l)x(W>>l) image with 16*4^l channels, channels
+// last, such that the reference's squeeze (models/RevResNet.py:34-37,
+//   out[(i*2+j)*D+d, h, w] = in[d, 2h+i, 2w+j]) is the identity on memory.
+// zc_offset returns the float offset of channel 0 of view pixel (y,x) inside one image.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int vst_level_of_channels(int c) { return c == 16 ? 0 : (c == 64 ? 1 : 2); }
+
+__device__ __forceinline__ size_t zc_offset(int level, int y, int x, int Wq) {
+    if (level == 0) {
+        const int cell = (y >> 2) * Wq + (x >> 2);
+        const int sub = ((((y >> 1) & 1) * 2 + ((x >> 1) & 1)) << 6) + (((y & 1) * 2 + (x & 1)) << 4);
+        return (size_t)cell * 256 + sub;
+    } else if (level == 1) {
+        const int cell = (y >> 1) * Wq + (x >> 1);
+        return (size_t)cell * 256 + (((y & 1) * 2 + (x & 1)) << 6);
+    }
+    return (size_t)(y * Wq + x) * 256;
+}
+
+// ReflectionPad2d(1) index for a coordinate that may be one past either end, clamped for
+// coordinates further out (those only feed outputs that are never stored).
+__device__ __forceinline__ int reflect_clamp(int v, int n) {
+    if (v < 0) v = -v;
+    if (v >= n) v = 2 * n - 2 - v;
+    v = v < 0 ? 0 : v;
+    return v >= n ? n - 1 : v;
+}
+
+static inline bool vst_shape_ok(int B, int H, int W) {
+    return B > 0 && H >= 8 && W >= 8 && (H % 4) == 0 && (W % 4) == 0;
+}
+
+// packed conv weights: [fp32 taps-major | bf16 hi frags | bf16 lo frags]
+struct PackedConvLayout {
+    int ksteps;       // number of 32-deep K steps (all chunks)
+    int coutp;        // cout padded to a multiple of 16
+    size_t f32_bytes; // 9*cin*cout*4 rounded up to 256
+    size_t frag_bytes;// ksteps*4*coutp*16 (per hi / lo section)
+};
+
+__host__ __device__ inline PackedConvLayout packed_conv_layout(int cout, int cin) {
+    PackedConvLayout p;
+    p.ksteps = cin >= 32 ? 9 * (cin / 32) : (cin == 16 ? 5 : 2);
+    p.coutp = (cout + 15) / 16 * 16;
+    p.f32_bytes = ((size_t)9 * cin * cout * 4 + 255) / 256 * 256;
+    p.frag_bytes = (size_t)p.ksteps * 4 * p.coutp * 16;
+    return p;
+}

@@ -1,0 +1,235 @@
+// Layout glue between the reference's NCHW tensors and the ZC state layout, and weight packing.
+//
+// Reference semantics restated here (paths relative to the reference root):
+//   split/merge            models/RevResNet.py:8-16    -> the two state halves s1 / s2
+//   injective_pad          models/RevResNet.py:19-31   -> zero channels 3..15 of s1, s2 = 0
+//   squeeze/unsqueeze      models/RevResNet.py:34-43   -> identity on the ZC layout
+//   channel_reduction "spread" :139-144 / its inverse :148-154 -> vst_spread / vst_gather
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// x[B,C,H,W] -> s1 (view level 0, 16 channels, C..15 zero)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x, float* __restrict__ s1,
+                                                         int C, int H, int W) {
+    const int xg = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int yg = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (xg >= W || yg >= H) return;
+    const size_t plane = (size_t)H * W;
+    const float* src = x + (size_t)b * C * plane + (size_t)yg * W + xg;
+    float v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] = c < C ? src[c * plane] : 0.f;
+    float* dst = s1 + (size_t)b * plane * 16 + zc_offset(0, yg, xg, W >> 2);
+#pragma unroll
+    for (int c = 0; c < 16; c += 4) *(float4*)(dst + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
+}
+
+__global__ __launch_bounds__(256) void unpack_output_kernel(const float* __restrict__ s1, float* __restrict__ x,
+                                                            int C, int H, int W) {
+    const int xg = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int yg = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (xg >= W || yg >= H) return;
+    const size_t plane = (size_t)H * W;
+    const float* src = s1 + (size_t)b * plane * 16 + zc_offset(0, yg, xg, W >> 2);
+    float* dst = x + (size_t)b * C * plane + (size_t)yg * W + xg;
+    for (int c = 0; c < C; ++c) dst[c * plane] = src[c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// spread / gather.  m = cat(s1, s2) has 512 channels per quarter-res cell.
+//   SP == 2:  z[d32 , 4h+2i+i', 4w+2j+j'] = m[(2i+j)*128 + (2i'+j')*32 + d32 ][h][w]
+//   SP == 1:  z[d128, 2h+i    , 2w+j    ] = m[(2i+j)*128 + d128             ][h][w]
+// i selects the half (i=0 -> s1, i=1 -> s2).  One workgroup moves 16 cells x both halves through a
+// skewed LDS image so that both the state side (float4 per lane) and the z side (one row segment per
+// wave) are coalesced and the z-side LDS accesses hit 32 distinct banks per half-wave.
+// ------------------------------------------------------------------------------------------------
+template <int SP>
+struct SpreadGeom {
+    static constexpr int CELL_STRIDE = SP == 2 ? 260 : 258;  // == 4 (resp. 2) mod 32
+    __device__ static __forceinline__ int lds_index(int slot, int c) {
+        if (SP == 2) {
+            const int g = c >> 5, d = c & 31;                  // g = 4j + 2i' + j'
+            return slot * 260 + (g >> 2) * 130 + ((g >> 1) & 1) * 64 + (g & 1) * 33 + d;
+        } else {
+            return slot * 258 + (c >> 7) * 129 + (c & 127);
+        }
+    }
+};
+
+template <int SP, bool TO_Z>
+__global__ __launch_bounds__(256) void spread_gather_kernel(float* __restrict__ s1, float* __restrict__ s2,
+                                                            float* __restrict__ z, int H, int W) {
+    __shared__ float lds[32 * SpreadGeom<SP>::CELL_STRIDE];
+    const int Hq = H >> 2, Wq = W >> 2;
+    const int w0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
+    const int t = threadIdx.x;
+    const size_t img = (size_t)Hq * Wq * 256;
+    float* half[2] = {s1 + (size_t)b * img, s2 + (size_t)b * img};
+
+    auto state_phase = [&]() {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 256 + t;
+            const int slot = idx >> 6, q = idx & 63;
+            const int w = w0 + (slot & 15);
+            if (w >= Wq) continue;
+            float* p = half[slot >> 4] + ((size_t)h * Wq + w) * 256 + q * 4;
+            const int li = SpreadGeom<SP>::lds_index(slot, q * 4);
+            if (TO_Z) {
+                const float4 v = *(const float4*)p;
+                lds[li] = v.x; lds[li + 1] = v.y; lds[li + 2] = v.z; lds[li + 3] = v.w;
+            } else {
+                *(float4*)p = make_float4(lds[li], lds[li + 1], lds[li + 2], lds[li + 3]);
+            }
+        }
+    };
+    auto z_phase = [&]() {
+        if (SP == 2) {
+            const int X = t & 63, wave = t >> 6;
+            const int wl = X >> 2, j = (X >> 1) & 1, jp = X & 1;
+            const int xg = w0 * 4 + X;
+            for (int it = 0; it < 32; ++it) {
+                const int combo = it * 4 + wave;          // (d32, Yl)
+                const int d = combo >> 2, Yl = combo & 3;
+                const int i = Yl >> 1, ip = Yl & 1;
+                if (xg >= W) continue;
+                float* p = z + (((size_t)b * 32 + d) * H + (4 * h + Yl)) * W + xg;
+                const int li = (i * 16 + wl) * 260 + j * 130 + ip * 64 + jp * 33 + d;
+                if (TO_Z) *p = lds[li]; else lds[li] = *p;
+            }
+        } else {
+            const int H2 = H >> 1, W2 = W >> 1;
+            const int X = t & 31, dsel = (t >> 5) & 1, wave = t >> 6;
+            const int wl = X >> 1, j = X & 1;
+            const int xg = w0 * 2 + X;
+            for (int it = 0; it < 32; ++it) {
+                const int combo = (it * 4 + wave) * 2 + dsel;   // (d128, i)
+                const int d = combo >> 1, i = combo & 1;
+                if (xg >= W2) continue;
+                float* p = z + (((size_t)b * 128 + d) * H2 + (2 * h + i)) * W2 + xg;
+                const int li = (i * 16 + wl) * 258 + j * 129 + d;
+                if (TO_Z) *p = lds[li]; else lds[li] = *p;
+            }
+        }
+    };
+    if (TO_Z) { state_phase(); __syncthreads(); z_phase(); }
+    else      { z_phase(); __syncthreads(); state_phase(); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: OIHW fp32 -> [fp32 [tap][ci][co] | bf16 hi [kstep][kg][coutp][8] | bf16 lo ...]
+// K ordering of the MFMA kernel (conv_mfma.hip, k_to_tap_ci):
+//   cin >= 32: kstep = chunk*9 + tap, k = kg*8+j -> ci = chunk*32 + k
+//   cin == 16: kstep s covers taps 2s, 2s+1:   tap = 2s + (kg>>1), ci = (kg&1)*8 + j
+//   cin ==  4: kstep s covers taps 8s..8s+7:   tap = 8s + 2kg + (j>>2), ci = j&3
+// taps > 8 and co >= cout are zero.
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_conv_kernel(const float* __restrict__ w, int cout, int cin, unsigned char* __restrict__ packed) {
+    const PackedConvLayout L = packed_conv_layout(cout, cin);
+    const size_t n_f32 = (size_t)9 * cin * cout;
+    const size_t n_frag = (size_t)L.ksteps * 4 * L.coutp * 8;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n_f32) {
+        const int co = idx % cout;
+        const int ci = (idx / cout) % cin;
+        const int tap = idx / ((size_t)cout * cin);
+        ((float*)packed)[idx] = w[((size_t)co * cin + ci) * 9 + tap];
+    }
+    if (idx < n_frag) {
+        const int j = idx & 7;
+        const int co = (idx >> 3) % L.coutp;
+        const int kg = (idx >> 3) / L.coutp % 4;
+        const int ks = (idx >> 3) / L.coutp / 4;
+        int tap, ci;
+        if (cin >= 32) { tap = ks % 9; ci = (ks / 9) * 32 + kg * 8 + j; }
+        else if (cin == 16) { tap = 2 * ks + (kg >> 1); ci = (kg & 1) * 8 + j; }
+        else { tap = 8 * ks + 2 * kg + (j >> 2); ci = j & 3; }
+        float v = 0.f;
+        if (tap < 9 && co < cout && ci < cin) v = w[((size_t)co * cin + ci) * 9 + tap];
+        const __bf16 hi = (__bf16)v;
+        const __bf16 lo = (__bf16)(v - (float)hi);
+        ((__bf16*)(packed + L.f32_bytes))[idx] = hi;
+        ((__bf16*)(packed + L.f32_bytes + L.frag_bytes))[idx] = lo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int vst_version(void) { return 100; }
+
+const char* vst_error_string(int code) {
+    switch (code) {
+        case VST_OK: return "ok";
+        case VST_E_ARG: return "invalid argument (null pointer or non-positive size)";
+        case VST_E_SHAPE: return "unsupported shape (H, W must be multiples of 4 and >= 8; channels in the documented sets)";
+        case VST_E_MODE: return "unknown mode (precision / sp_steps / direction)";
+        case VST_E_WORKSPACE: return "workspace too small or null";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown vstnet error";
+    }
+}
+
+size_t vst_conv_packed_bytes(int cout, int cin) {
+    const PackedConvLayout L = packed_conv_layout(cout, cin);
+    return L.f32_bytes + 2 * L.frag_bytes;
+}
+
+int vst_pack_conv(const float* w, int cout, int cin, void* packed, void* stream) {
+    if (!w || !packed || cout <= 0) return VST_E_ARG;
+    if (!(cin == 4 || cin == 16 || (cin >= 32 && cin % 32 == 0))) return VST_E_SHAPE;
+    const PackedConvLayout L = packed_conv_layout(cout, cin);
+    size_t n = (size_t)9 * cin * cout;
+    const size_t n_frag = (size_t)L.ksteps * 4 * L.coutp * 8;
+    if (n_frag > n) n = n_frag;
+    pack_conv_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, (hipStream_t)stream>>>(w, cout, cin, (unsigned char*)packed);
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
+int vst_pack_input(const float* x, float* s1, float* s2, int B, int C, int H, int W, void* stream) {
+    if (!x || !s1 || !s2) return VST_E_ARG;
+    if (!vst_shape_ok(B, H, W) || C < 1 || C > 16) return VST_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(s2, 0, (size_t)B * H * W * 16 * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    pack_input_kernel<<<dim3((W + 63) / 64, (H + 3) / 4, B), 256, 0, st>>>(x, s1, C, H, W);
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
+int vst_unpack_output(const float* s1, float* x, int B, int C, int H, int W, void* stream) {
+    if (!x || !s1) return VST_E_ARG;
+    if (!vst_shape_ok(B, H, W) || C < 1 || C > 16) return VST_E_SHAPE;
+    unpack_output_kernel<<<dim3((W + 63) / 64, (H + 3) / 4, B), 256, 0, (hipStream_t)stream>>>(s1, x, C, H, W);
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
+int vst_spread(const float* s1, const float* s2, float* z, int B, int H, int W, int sp_steps, void* stream) {
+    if (!s1 || !s2 || !z) return VST_E_ARG;
+    if (!vst_shape_ok(B, H, W)) return VST_E_SHAPE;
+    const dim3 grid((W / 4 + 15) / 16, H / 4, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (sp_steps == 2) spread_gather_kernel<2, true><<<grid, 256, 0, st>>>((float*)s1, (float*)s2, z, H, W);
+    else if (sp_steps == 1) spread_gather_kernel<1, true><<<grid, 256, 0, st>>>((float*)s1, (float*)s2, z, H, W);
+    else return VST_E_MODE;
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
+int vst_gather(const float* z, float* s1, float* s2, int B, int H, int W, int sp_steps, void* stream) {
+    if (!s1 || !s2 || !z) return VST_E_ARG;
+    if (!vst_shape_ok(B, H, W)) return VST_E_SHAPE;
+    const dim3 grid((W / 4 + 15) / 16, H / 4, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (sp_steps == 2) spread_gather_kernel<2, false><<<grid, 256, 0, st>>>(s1, s2, (float*)z, H, W);
+    else if (sp_steps == 1) spread_gather_kernel<1, false><<<grid, 256, 0, st>>>(s1, s2, (float*)z, H, W);
+    else return VST_E_MODE;
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,206 @@
+"""RevResNet — drop-in for the reference's ``models.RevResNet.RevResNet`` on MI355X.
+
+Same constructor, attributes, call convention and state_dict keys as the reference
+(models/RevResNet.py:166-239): ``net(x, forward=True)`` encodes ``x[B,3,H,W]`` to
+``z[B,32,H,W]`` (photorealistic: hidden_dim=16, sp_steps=2) or ``z[B,128,H/2,W/2]`` (artistic: 64, 1);
+``net(z, forward=False)`` is the exact inverse with recomputed activations.  All device work goes
+through the C ABI of ``libvstnet_hip.so`` (include/vstnet.h); there is no CPU or torch-op fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .synth import STACK, CONV_IDX
+
+_PRECISIONS = {"bf16x3": _lib.PREC_BF16X3, "fp32": _lib.PREC_FP32}
+
+
+def _stream_ptr() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class residual_block(nn.Module):
+    """Parameter container with the reference's layout (models/RevResNet.py:68-94): ``conv`` is a
+    Sequential whose entries 1, 4, 7 are the three 3x3 convolutions (the others are placeholders
+    for ReflectionPad2d / ReLU, which the HIP kernels fuse)."""
+
+    def __init__(self, channel, stride=1, mult=4, kernel=3):
+        super().__init__()
+        self.stride = stride
+        self.channel = channel
+        in_ch = channel if stride == 1 else channel // 4
+        mid = channel // mult
+        self.conv = nn.Sequential(
+            nn.Identity(), nn.Conv2d(in_ch, mid, kernel, stride=stride, padding=0, bias=True), nn.Identity(),
+            nn.Identity(), nn.Conv2d(mid, mid, kernel, padding=0, bias=True), nn.Identity(),
+            nn.Identity(), nn.Conv2d(mid, channel, kernel, padding=0, bias=True),
+        )
+        for m in self.conv:                       # reference init_layers(): zero biases
+            if isinstance(m, nn.Conv2d):
+                m.bias.data.zero_()
+
+
+class channel_reduction(nn.Module):
+    """models/RevResNet.py:119-129 (pad = out_ch*4**sp_steps - in_ch must be 0, as in both modes)."""
+
+    def __init__(self, in_ch, out_ch, sp_steps=2, n_blocks=2, kernel=3):
+        super().__init__()
+        self.pad = out_ch * 4 ** sp_steps - in_ch
+        self.sp_steps = sp_steps
+        self.n_blocks = n_blocks
+        self.block_list = nn.ModuleList(
+            [residual_block(out_ch * 4 ** sp_steps, stride=1, mult=4, kernel=kernel) for _ in range(n_blocks)])
+
+
+class RevResNet(nn.Module):
+    def __init__(self, nBlocks=[10, 10, 10], nStrides=[1, 2, 2], nChannels=[16, 64, 256], in_channel=3, mult=4,
+                 hidden_dim=16, sp_steps=2, kernel=3, precision=None):
+        super().__init__()
+        if (list(nBlocks), list(nStrides), list(nChannels or []), mult, kernel) != ([10, 10, 10], [1, 2, 2],
+                                                                                    [16, 64, 256], 4, 3):
+            raise NotImplementedError("the HIP path implements the published CAP-VSTNet architecture only "
+                                      "(nBlocks=[10,10,10], nStrides=[1,2,2], nChannels=[16,64,256], mult=4, kernel=3)")
+        if sp_steps not in (1, 2) or hidden_dim * 4 ** sp_steps != 256 or not (1 <= in_channel <= 16):
+            raise NotImplementedError("supported modes: (hidden_dim=16, sp_steps=2) and (hidden_dim=64, sp_steps=1)")
+        self.nBlocks = nBlocks
+        self.in_channel = in_channel
+        self.pad = 2 * nChannels[0] - in_channel
+        self.in_ch = nChannels[0]
+        self.down_scale = np.prod(np.array(nStrides))
+        self.hidden_dim = hidden_dim
+        self.sp_steps = sp_steps
+        self.stack = nn.ModuleList([residual_block(ch, stride, mult=mult, kernel=kernel) for stride, ch in STACK])
+        self.channel_reduction = channel_reduction(nChannels[-1], hidden_dim, sp_steps=sp_steps, kernel=kernel)
+        precision = precision or os.environ.get("VST_PRECISION", "bf16x3")
+        if precision not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+        self.precision = precision
+        self._packed = None          # (device, blob tensor, bias tensors, NetWeights struct)
+        self._workspace = None
+
+    # ------------------------------------------------------------------ weight packing
+    def _blocks(self):
+        return list(self.stack) + list(self.channel_reduction.block_list)
+
+    def _invalidate(self):
+        self._packed = None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._invalidate()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._invalidate()
+        return out
+
+    def refresh_weights(self):
+        """Call after editing parameters in place (the packed copies are rebuilt on the next call)."""
+        self._invalidate()
+
+    def _ensure_packed(self, device):
+        if self._packed is not None and self._packed[0] == device:
+            return self._packed[3]
+        L = _lib.lib()
+        convs = []
+        for blk in self._blocks():
+            for ci in CONV_IDX:
+                convs.append(blk.conv[ci])
+        sizes = [L.vst_conv_packed_bytes(c.out_channels, c.in_channels) for c in convs]
+        offsets = np.concatenate([[0], np.cumsum([(s + 255) // 256 * 256 for s in sizes])])
+        blob = torch.empty(int(offsets[-1]), dtype=torch.uint8, device=device)
+        biases = []
+        net = _lib.NetWeights()
+        with torch.cuda.device(device):
+            st = _stream_ptr()
+            for k, c in enumerate(convs):
+                if c.weight.device != device:
+                    raise RuntimeError(f"RevResNet parameters live on {c.weight.device}, input on {device}: call .to(device)")
+                w = c.weight.detach().to(torch.float32).contiguous()
+                b = c.bias.detach().to(torch.float32).contiguous()
+                biases.append((w, b))
+                _lib.check(L.vst_pack_conv(C.c_void_p(w.data_ptr()), c.out_channels, c.in_channels,
+                                           C.c_void_p(blob.data_ptr() + int(offsets[k])), st), "vst_pack_conv")
+                cw = net.blocks[k // 3].conv[k % 3]
+                cw.packed = blob.data_ptr() + int(offsets[k])
+                cw.bias = b.data_ptr()
+        self._packed = (device, blob, biases, net)
+        return net
+
+    def _get_workspace(self, nbytes, device):
+        ws = self._workspace
+        if ws is None or ws.device != device or ws.numel() < nbytes:
+            self._workspace = ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return ws
+
+    # ------------------------------------------------------------------ the reference's call surface
+    def forward(self, x, forward=True):
+        return self._forward(x) if forward else self._inverse(x)
+
+    def _check(self, t, channels, what):
+        if not t.is_cuda:
+            raise RuntimeError("vstnet_amd.RevResNet runs on ROCm devices only (no CPU fallback): move the "
+                               "module and its inputs to 'cuda'")
+        if t.dim() != 4 or t.shape[1] != channels:
+            raise RuntimeError(f"{what}: expected [B,{channels},H,W], got {tuple(t.shape)}")
+        return t.detach().to(torch.float32).contiguous()
+
+    def _forward(self, x):
+        """models/RevResNet.py:210-223."""
+        x = self._check(x, self.in_channel, "RevResNet forward input")
+        B, _, H, W = x.shape
+        if H % 4 or W % 4 or H < 8 or W < 8:
+            raise RuntimeError(f"H and W must be multiples of 4 and >= 8 (got {H}x{W})")
+        L = _lib.lib()
+        net = self._ensure_packed(x.device)
+        s = self.sp_steps
+        z = torch.empty((B, 32, H, W) if s == 2 else (B, 128, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        ws = self._get_workspace(L.vst_pass_workspace_bytes(B, H, W), x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.vst_revnet_forward(C.byref(net), C.c_void_p(x.data_ptr()), C.c_void_p(z.data_ptr()),
+                                            C.c_void_p(ws.data_ptr()), B, self.in_channel, H, W, s,
+                                            _PRECISIONS[self.precision], _stream_ptr()), "vst_revnet_forward")
+        return z
+
+    def _inverse(self, z):
+        """models/RevResNet.py:225-239."""
+        s = self.sp_steps
+        z = self._check(z, 32 if s == 2 else 128, "RevResNet inverse input")
+        B = z.shape[0]
+        H, W = (z.shape[2], z.shape[3]) if s == 2 else (z.shape[2] * 2, z.shape[3] * 2)
+        if H % 4 or W % 4 or H < 8 or W < 8:
+            raise RuntimeError(f"code resolution must correspond to H, W multiples of 4 and >= 8 (got {H}x{W})")
+        L = _lib.lib()
+        net = self._ensure_packed(z.device)
+        x = torch.empty((B, self.in_channel, H, W), dtype=torch.float32, device=z.device)
+        ws = self._get_workspace(L.vst_pass_workspace_bytes(B, H, W), z.device)
+        with torch.cuda.device(z.device):
+            _lib.check(L.vst_revnet_inverse(C.byref(net), C.c_void_p(z.data_ptr()), C.c_void_p(x.data_ptr()),
+                                            C.c_void_p(ws.data_ptr()), B, self.in_channel, H, W, s,
+                                            _PRECISIONS[self.precision], _stream_ptr()), "vst_revnet_inverse")
+        return x
+
+    @torch.no_grad()
+    def sample(self, transfer_module, x_c, x_s, device):
+        """models/RevResNet.py:241-263 (training-log helper; the fork's pdb trap is dropped)."""
+        was_training = self.training
+        self.eval()
+        x_cs, x_c_cyc = [], []
+        for i in range(x_c.size(0)):
+            z_c = self(x_c[i].unsqueeze(0).to(device))
+            z_s = self(x_s[i].unsqueeze(0).to(device))
+            stylized = self(transfer_module.transfer(z_c, z_s), forward=False)
+            z_cs = self(stylized)
+            rec = self(transfer_module.transfer(z_cs, z_c), forward=False)
+            x_cs.append(stylized.cpu())
+            x_c_cyc.append(rec.cpu())
+        if was_training:
+            self.train()
+        return x_c, x_s, torch.cat(x_cs), torch.cat(x_c_cyc)
