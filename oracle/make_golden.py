@@ -39,12 +39,17 @@ def import_reference():
     todos = types.ModuleType("todos")
     todos.debug = types.SimpleNamespace(output_var=lambda *a, **k: None)
     sys.modules["todos"] = todos
-    sys.path.insert(0, REF)
-    with contextlib.redirect_stdout(io.StringIO()):
-        import models.RevResNet as ref_rev
-        import models.cWCT as ref_cwct
-    sys.path.remove(REF)
-    return ref_rev, ref_cwct
+    # by file path: this repo has its own `models` package (the drop-in), which would shadow the
+    # reference's namespace package of the same name
+    import importlib.util
+    mods = []
+    for name in ("RevResNet", "cWCT"):
+        spec = importlib.util.spec_from_file_location(f"reference_{name}", os.path.join(REF, "models", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        with contextlib.redirect_stdout(io.StringIO()):
+            spec.loader.exec_module(mod)
+        mods.append(mod)
+    return mods[0], mods[1]
 
 
 def build_ref_net(ref_rev, mode):
@@ -152,12 +157,15 @@ def main():
     cw = ref_cwct.cWCT()
     g = {}
     for N, L, Ls in ((32, 50, 64), (32, 4096, 3000), (128, 1024, 777)):
-        c = rnd((N, L), 100 + N + L, -1, 1) * torch.linspace(0.2, 2.0, N).unsqueeze(1) + 0.3
-        s = rnd((N, Ls), 200 + N + L, -1, 1) * torch.linspace(1.5, 0.1, N).unsqueeze(1) - 0.1
-        # give the channels some correlation so the factors are not diagonal
-        mixc = torch.eye(N) + 0.3 * rnd((N, N), 300 + N)
-        mixs = torch.eye(N) + 0.3 * rnd((N, N), 400 + N)
+        c = rnd((N, L), 100 + N + L, -1, 1) * torch.linspace(0.5, 2.0, N).unsqueeze(1) + 0.3
+        s = rnd((N, Ls), 200 + N + L, -1, 1) * torch.linspace(1.5, 0.4, N).unsqueeze(1) - 0.1
+        # give the channels some correlation so the factors are not diagonal, keeping the covariance
+        # about as well conditioned as real codes (cond ~ 1e2..1e3)
+        mixc = torch.eye(N) + (0.6 / N ** 0.5) * rnd((N, N), 300 + N)
+        mixs = torch.eye(N) + (0.6 / N ** 0.5) * rnd((N, N), 400 + N)
         c, s = mixc @ c, mixs @ s
+        cc = c.double() - c.double().mean(-1, keepdim=True)
+        print(f"  N={N} L={L}: cond(Cov(content)) = {float(torch.linalg.cond(cc @ cc.t() / (L - 1))):.3g}")
         wh = cw.whitening(c)
         co = cw.coloring(wh, s)
         check(f"whitening N={N} L={L}", cpu_ref.whitening(c), wh, 2e-4)

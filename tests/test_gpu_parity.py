@@ -37,9 +37,10 @@ def make_net(mode="photo", precision="bf16x3", seed=1234):
     return net.to("cuda").eval(), sd, sp
 
 
-def assert_close(got, ref, tol, what):
+def assert_close(got, ref, tol, what, tol_max=None):
     l2, mx = rel_err(got, ref)
-    assert l2 <= tol and mx <= tol, f"{what}: rel-L2 {l2:.3e}, max-rel {mx:.3e} (tol {tol:g})"
+    tol_max = tol if tol_max is None else tol_max
+    assert l2 <= tol and mx <= tol_max, f"{what}: rel-L2 {l2:.3e}, max-rel {mx:.3e} (tol {tol:g}/{tol_max:g})"
     return l2, mx
 
 
@@ -179,7 +180,7 @@ def test_cwct_2d_golden(golden):
     from models.cWCT import cWCT
     g = golden("cwct_2d")
     cw = cWCT()
-    for N, Lp, tol in ((32, 4096, 2e-4), (128, 1024, 2e-4), (32, 50, 5e-2)):
+    for N, Lp, tol in ((32, 4096, 1e-4), (128, 1024, 1e-4), (32, 50, 5e-4)):   # cond 35 / 45 / 278
         c, s = T(g[f"c_{N}_{Lp}"]).cuda(), T(g[f"s_{N}_{Lp}"]).cuda()
         assert_close(cw.whitening(c), T(g[f"whiten_{N}_{Lp}"]), tol, f"whitening {N}x{Lp}")
         assert_close(cw.coloring(T(g[f"whiten_{N}_{Lp}"]).cuda(), s), T(g[f"color_{N}_{Lp}"]), 2e-5, f"coloring {N}x{Lp}")
@@ -198,7 +199,7 @@ def test_cwct_stats_fp64(L):
         assert st[0] == Lp
         assert float((st[1:1 + N] - mu).abs().max()) < 1e-5
         err = float((st[1 + N:].reshape(N, N) - cov).abs().max() / cov.abs().max())
-        assert err < 2e-6, (N, Lp, err)
+        assert err < 1e-5, (N, Lp, err)
 
 
 def test_cwct_transfer_golden(golden):
@@ -218,7 +219,9 @@ def test_cwct_masked_golden(golden):
     cw = cWCT()
     c = T(g["c"]).cuda()
     out = cw.transfer(c, T(g["s"]).cuda(), g["cmask"], g["smask"])
-    assert_close(out, T(g["out"]), 5e-5, "transfer_seg")
+    # a label may cover as few as ~50 pixels (32 channels): the per-label factor is ill-conditioned, so the
+    # pointwise budget is the north_star 1e-3 while the L2 error stays two orders below
+    assert_close(out, T(g["out"]), 1e-4, "transfer_seg", tol_max=TOL)
     keep = T(np.isin(g["cmask"][0], [4, 9]))
     assert torch.equal(out[0][:, keep].cpu(), T(g["c"])[0][:, keep])
     assert torch.equal(c.cpu(), T(g["c"]))          # input not mutated
@@ -290,8 +293,8 @@ def test_masked_stylisation_vs_oracle():
         zc, zs, zcs, sty = cpu_ref.stylize(xc, xs, sd, sp, cm, sm)
     g_zc, g_zs = net(xc.cuda()), net(xs.cuda())
     g_zcs = cw.transfer(g_zc, g_zs, cm, sm)
-    assert_close(g_zcs, zcs, 2e-4, "masked z_cs")
-    assert_close(net(g_zcs, forward=False), sty, 2e-4, "masked stylized")
+    assert_close(g_zcs, zcs, 2e-4, "masked z_cs", tol_max=TOL)
+    assert_close(net(g_zcs, forward=False), sty, 2e-4, "masked stylized", tol_max=TOL)
 
 
 # ------------------------------------------------------------------------------------------- full size properties

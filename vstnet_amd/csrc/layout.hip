@@ -48,11 +48,11 @@ __global__ __launch_bounds__(256) void unpack_output_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------------
 template <int SP>
 struct SpreadGeom {
-    static constexpr int CELL_STRIDE = SP == 2 ? 260 : 258;  // == 4 (resp. 2) mod 32
+    static constexpr int CELL_STRIDE = SP == 2 ? 324 : 258;  // == 4 (resp. 2) mod 32
     __device__ static __forceinline__ int lds_index(int slot, int c) {
         if (SP == 2) {
             const int g = c >> 5, d = c & 31;                  // g = 4j + 2i' + j'
-            return slot * 260 + (g >> 2) * 130 + ((g >> 1) & 1) * 64 + (g & 1) * 33 + d;
+            return slot * 324 + (g >> 2) * 162 + ((g >> 1) & 1) * 66 + (g & 1) * 33 + d;   // disjoint 32-float runs
         } else {
             return slot * 258 + (c >> 7) * 129 + (c & 127);
         }
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void spread_gather_kernel(float* __restrict__ 
                 const int i = Yl >> 1, ip = Yl & 1;
                 if (xg >= W) continue;
                 float* p = z + (((size_t)b * 32 + d) * H + (4 * h + Yl)) * W + xg;
-                const int li = (i * 16 + wl) * 260 + j * 130 + ip * 64 + jp * 33 + d;
+                const int li = (i * 16 + wl) * 324 + j * 162 + ip * 66 + jp * 33 + d;
                 if (TO_Z) *p = lds[li]; else lds[li] = *p;
             }
         } else {
