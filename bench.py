@@ -154,13 +154,26 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cores():
+    """CPU share of this process: affinity mask, capped by the cgroup quota (the GPU box exposes every host
+    core in os.cpu_count() but schedules the job on a 16-core share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("VST_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(sd, sp, S):
     """The oracle (CPU restatement of the reference's torch-op sequence) timed on this host's cores on ONE
     frame of the same workload (style code precomputed, like the GPU leg)."""
     import torch
     from oracle import cpu_ref
     from vstnet_amd.synth import synthetic_frames
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     xc, xs = synthetic_frames(1, S, S, seed=0), synthetic_frames(1, S, S, seed=1)
     with torch.no_grad():

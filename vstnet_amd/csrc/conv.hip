@@ -72,6 +72,67 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
     lo = __builtin_bit_cast(uint2, l);
 }
 
+// ---- register epilogue ---------------------------------------------------------------------------
+// The MFMAs are issued as D = W * X^T (weights are the A operand, pixels the B operand), so lane
+// (lrow, kg) ends up with D[co = 4*kg + r][pixel = lrow]: four CONSECUTIVE channels of one pixel per
+// accumulator -> one float4 store (or float4 read-modify-write of the state) per 16x16 tile, no LDS.
+template <int COUT, int NB>
+__device__ __forceinline__ void load_bias(const ConvArgs& a, int co_lane, float4 (&bias)[NB]) {
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+        bias[n] = co_lane + n * 16 < COUT ? *(const float4*)(a.bias + co_lane + n * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// address of the 4 channels [co_lane + 16 n, +4) of output pixel (oy, ox); nullptr when outside the image / channel range
+template <int COUT, bool OUT_STATE, bool FULL = false>
+__device__ __forceinline__ float4* out_ptr(const ConvArgs& a, float* out_img, int oy, int ox, int co) {
+    if (!FULL && (oy >= a.Hout || ox >= a.Wout || co >= COUT)) return nullptr;
+    if (OUT_STATE) return (float4*)(out_img + zc_offset(vst_level_of_channels(COUT), oy, ox, a.Wq) + co);
+    return (float4*)(out_img + ((size_t)oy * a.Wout + ox) * COUT + co);
+}
+
+template <int COUT, int MR, int NB, bool FULL = false>
+__device__ __forceinline__ void load_old(const ConvArgs& a, float* out_img, int oy0, int ox, int co_lane,
+                                         float4 (&old)[MR][NB]) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const float4* p = out_ptr<COUT, true, FULL>(a, out_img, oy0 + m, ox, co_lane + n * 16);
+            old[m][n] = (FULL || p) ? *p : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+}
+
+// OUT_STATE: out = old + sign * (acc + bias);  else: out = relu(acc + bias)
+template <int COUT, bool OUT_STATE, int MR, int NB, bool FULL = false>
+__device__ __forceinline__ void store_tile(const ConvArgs& a, float* out_img, int oy0, int ox, int co_lane,
+                                           const f32x4 (&acc)[MR][NB], const float4 (&bias)[NB],
+                                           const float4 (&old)[MR][NB]) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            float4* p = out_ptr<COUT, OUT_STATE, FULL>(a, out_img, oy0 + m, ox, co_lane + n * 16);
+            if (!FULL && !p) continue;
+            float4 r = make_float4(acc[m][n][0] + bias[n].x, acc[m][n][1] + bias[n].y, acc[m][n][2] + bias[n].z,
+                                   acc[m][n][3] + bias[n].w);
+            if (OUT_STATE) {
+                const float4 o = old[m][n];
+                r = make_float4(o.x + a.sign * r.x, o.y + a.sign * r.y, o.z + a.sign * r.z, o.w + a.sign * r.w);
+            } else {
+                r.x = r.x > 0.f ? r.x : 0.f; r.y = r.y > 0.f ? r.y : 0.f;
+                r.z = r.z > 0.f ? r.z : 0.f; r.w = r.w > 0.f ? r.w : 0.f;
+            }
+            *p = r;
+        }
+}
+
+#define MFMA3(acc, wh, wl, xh, xl)                                              \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc, 0, 0, 0);        \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc, 0, 0, 0);        \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc, 0, 0, 0)
+
+// ---- generic kernel: synchronous staging per input-channel chunk (all shapes) ----------------------
 template <int CIN, int COUT, int STRIDE, bool IN_STATE, bool OUT_STATE>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     using C = ConvCfg<CIN, COUT, STRIDE>;
@@ -160,79 +221,259 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         // ---- MFMA over the chunk's k steps ---------------------------------------------------------
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) {
-            bf16x8 bh[C::NB], bl[C::NB];
+            bf16x8 wh[C::NB], wl[C::NB];
 #pragma unroll
             for (int n = 0; n < C::NB; ++n) {
                 const int boff = ((ks * 4 + kg) * C::NT + n * 16 + lrow) * 16;
-                bh[n] = __builtin_bit_cast(bf16x8, *(const uint4*)(b_hi + boff));
-                bl[n] = __builtin_bit_cast(bf16x8, *(const uint4*)(b_lo + boff));
+                wh[n] = __builtin_bit_cast(bf16x8, *(const uint4*)(b_hi + boff));
+                wl[n] = __builtin_bit_cast(bf16x8, *(const uint4*)(b_lo + boff));
             }
 #pragma unroll
             for (int m = 0; m < C::MR; ++m) {
-                bf16x8 ah, al;
+                bf16x8 xh, xl;
                 if (CIN >= 32) {
                     const int dy = ks / 3, dx = ks - dy * 3;
                     const int slot = slot_base + (m * STRIDE + dy) * C::IW + dx;
                     const int aoff = (kg * C::NSLOT + slot) * 16;
-                    ah = __builtin_bit_cast(bf16x8, *(const uint4*)(a_hi + aoff));
-                    al = __builtin_bit_cast(bf16x8, *(const uint4*)(a_lo + aoff));
+                    xh = __builtin_bit_cast(bf16x8, *(const uint4*)(a_hi + aoff));
+                    xl = __builtin_bit_cast(bf16x8, *(const uint4*)(a_lo + aoff));
                 } else if (CIN == 16) {
                     int tap = 2 * ks + (kg >> 1);
                     tap = tap > 8 ? 8 : tap;
                     const int dy = tap / 3, dx = tap - dy * 3;
                     const int slot = slot_base + (m * STRIDE + dy) * C::IW + dx;
                     const int aoff = ((kg & 1) * C::NSLOT + slot) * 16;
-                    ah = __builtin_bit_cast(bf16x8, *(const uint4*)(a_hi + aoff));
-                    al = __builtin_bit_cast(bf16x8, *(const uint4*)(a_lo + aoff));
+                    xh = __builtin_bit_cast(bf16x8, *(const uint4*)(a_hi + aoff));
+                    xl = __builtin_bit_cast(bf16x8, *(const uint4*)(a_lo + aoff));
                 } else {
                     int t0 = 8 * ks + 2 * kg;
                     t0 = t0 > 8 ? 8 : t0;
                     const int t1 = t0 + 1 > 8 ? 8 : t0 + 1;
                     const int s0 = slot_base + (m * STRIDE + t0 / 3) * C::IW + t0 % 3;
                     const int s1 = slot_base + (m * STRIDE + t1 / 3) * C::IW + t1 % 3;
-                    uint4 h, l;
                     const uint2 h0 = *(const uint2*)(a_hi + s0 * 8), h1 = *(const uint2*)(a_hi + s1 * 8);
                     const uint2 l0 = *(const uint2*)(a_lo + s0 * 8), l1 = *(const uint2*)(a_lo + s1 * 8);
-                    h = make_uint4(h0.x, h0.y, h1.x, h1.y);
-                    l = make_uint4(l0.x, l0.y, l1.x, l1.y);
-                    ah = __builtin_bit_cast(bf16x8, h);
-                    al = __builtin_bit_cast(bf16x8, l);
+                    xh = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+                    xl = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
                 }
 #pragma unroll
-                for (int n = 0; n < C::NB; ++n) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
-                }
+                for (int n = 0; n < C::NB; ++n) { MFMA3(acc[m][n], wh[n], wl[n], xh, xl); }
             }
         }
     }
 
-    // ---- epilogue: D[row = pixel 4*kg + r][col = channel lrow] -----------------------------------------
     float* const out_img = a.out + (size_t)b * a.out_img_stride;
+    float4 bias[C::NB], old[C::MR][C::NB];
+    load_bias<COUT, C::NB>(a, co0 + 4 * kg, bias);
+    if (COUT % 16 == 0 && ty0 + C::TH <= a.Hout && tx0 + C::TW <= a.Wout) {      // interior tile: no predicates
+        if (OUT_STATE) load_old<COUT, C::MR, C::NB, true>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, old);
+        store_tile<COUT, OUT_STATE, C::MR, C::NB, true>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, acc, bias, old);
+    } else {
+        if (OUT_STATE) load_old<COUT, C::MR, C::NB>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, old);
+        store_tile<COUT, OUT_STATE, C::MR, C::NB>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, acc, bias, old);
+    }
+}
+
+// ---- pipelined kernel for the MFMA-bound shapes: CIN in {64,256}, COUT in {64,256}, stride 1 --------
+// A stage = (32-channel chunk, tap row dy) = 3 k-steps = 144 MFMAs per wave.  Two activation buffers
+// and two weight buffers in LDS; while stage s computes, the wave prefetches stage s+1's weights and a
+// third of the next chunk's activations into registers and writes them to the other buffers after its
+// MFMAs (one barrier per stage).  With COUT = 256 the four 64-channel output tiles are looped inside
+// the workgroup: the activation image (both chunks) stays resident, only weights stream.
+template <int CIN, int COUT>
+struct PipeCfg {
+    static constexpr int NW = 8, NTHR = 64 * NW;           // 8 waves: two per SIMD, each owns MR = 2 tile rows (== launch bounds)
+    static constexpr int NT = 64, NB = 4, MR = 16 / NW, IW = 18, NPIX = 324, NSLOT = 336;
+    static constexpr int NCHUNK = CIN / 32, NCOT = COUT / 64;
+    static constexpr int A_PLANE = 4 * NSLOT * 16, A_BUF = 2 * A_PLANE;       // 43008 (hi + lo planes of one 32-channel chunk)
+    static constexpr int B_PLANE = 3 * 4 * 64 * 16, B_BUF = 2 * B_PLANE;      // 24576 (hi + lo, 3 k-steps x 64 channels)
+    static constexpr int LDS_BYTES = 2 * A_BUF + 2 * B_BUF;                   // 135168
+    static constexpr int A_PART = NPIX * 4 / 3;                               // 432 (slot, cig) items per stage
+    static constexpr int A_ITEMS = (A_PART + NTHR - 1) / NTHR;                // per thread and part
+    static constexpr int B_ITEMS = 2 * 768 / NTHR;                            // uint4 per thread and stage
+};
+
+// Pipeline: a stage = (32-channel chunk, tap row dy) = 3 k-steps.  Two activation buffers and two weight
+// buffers in LDS.  While stage s computes, the wave issues the global loads of stage s+2's weights and of a
+// third of the next chunk's activations into registers (two register sets indexed by the compile-time
+// stage parity: six stages are unrolled per loop body) and writes what it loaded during stage s-1 into the
+// buffers of stage s+1; one barrier per stage.  Fragments are double-buffered in registers across k-steps.
+// With COUT = 256 the four 64-channel output slices are looped inside the workgroup: the activation image
+// (both chunks) stays resident, only weights stream.
+template <int CIN, int COUT, bool IN_STATE, bool OUT_STATE>
+__global__ __launch_bounds__(512) void conv_pipe_kernel(const ConvArgs a) {
+    using C = PipeCfg<CIN, COUT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const Abuf = smem;
+    unsigned char* const Bbuf = smem + 2 * C::A_BUF;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, kg = lane >> 4;
+    const int tx0 = blockIdx.x * 16, ty0 = blockIdx.y * 16, b = blockIdx.z;
+    const float* const in_img = a.in + (size_t)b * a.in_img_stride;
+    float* const out_img = a.out + (size_t)b * a.out_img_stride;
+    const PackedConvLayout PL = packed_conv_layout(COUT, CIN);
+    const unsigned char* const w_plane0 = a.packed + PL.f32_bytes;
+
+    // activation staging: each third ("part") of the 18x18 x (4 channel-groups) image is 432 (slot, cig)
+    // items, A_ITEMS per thread.  All uses index these arrays with compile-time constants (the tap-row
+    // stages are unrolled), so they stay in registers.  Threads past the end repeat the last item.
+    unsigned a_src[3][C::A_ITEMS], a_dst[3][C::A_ITEMS];
 #pragma unroll
-    for (int n = 0; n < C::NB; ++n) {
-        const int co = co0 + n * 16 + lrow;
-        if (co >= COUT) continue;
-        const float bias = a.bias[co];
+    for (int part = 0; part < 3; ++part)
+#pragma unroll
+        for (int it = 0; it < C::A_ITEMS; ++it) {
+            const int j = it * C::NTHR + tid;
+            const int idx = part * C::A_PART + (j < C::A_PART ? j : C::A_PART - 1);
+            const int cig = idx & 3, slot = idx >> 2;
+            const int iy = slot / C::IW, ix = slot - iy * C::IW;
+            const int gy = reflect_clamp(ty0 - 1 + iy, a.Hin), gx = reflect_clamp(tx0 - 1 + ix, a.Win);
+            const size_t off = IN_STATE ? zc_offset(vst_level_of_channels(CIN), gy, gx, a.Wq)
+                                        : ((size_t)gy * a.Win + gx) * CIN;
+            a_src[part][it] = (unsigned)(off + cig * 8);
+            a_dst[part][it] = (cig * C::NSLOT + slot) * 16;
+        }
+    struct APart { float4 v[C::A_ITEMS][2]; };
+    struct BStage { uint4 v[C::B_ITEMS]; };
+#define LOAD_A(r, chunk, part)                                                          \
+    _Pragma("unroll") for (int it_ = 0; it_ < C::A_ITEMS; ++it_) {                      \
+        const float* p_ = in_img + a_src[part][it_] + (chunk) * 32;                     \
+        r.v[it_][0] = *(const float4*)p_; r.v[it_][1] = *(const float4*)(p_ + 4);       \
+    }
+#define STORE_A(buf, part, r)                                                           \
+    _Pragma("unroll") for (int it_ = 0; it_ < C::A_ITEMS; ++it_) {                      \
+        unsigned char* base_ = Abuf + (buf) * C::A_BUF;                                 \
+        uint4 h_, l_;                                                                   \
+        split8(r.v[it_][0], r.v[it_][1], h_, l_);                                       \
+        *(uint4*)(base_ + a_dst[part][it_]) = h_;                                       \
+        *(uint4*)(base_ + C::A_PLANE + a_dst[part][it_]) = l_;                          \
+    }
+    // weights of stage (q = cot*NCHUNK + chunk, dy): 2 planes (hi, lo) x 3 k-steps x 256 uint4 = 1536 items
+    int b_off[C::B_ITEMS], b_dst[C::B_ITEMS];
+#pragma unroll
+    for (int it = 0; it < C::B_ITEMS; ++it) {
+        const int idx = it * C::NTHR + tid;
+        const int plane = idx >= 768, r = idx - plane * 768;
+        const int k3 = r >> 8, kgi = (r >> 6) & 3, co = r & 63;
+        b_off[it] = (int)(plane * PL.frag_bytes) + ((k3 * 4 + kgi) * COUT + co) * 16;
+        b_dst[it] = plane * C::B_PLANE + r * 16;
+    }
+    auto load_b = [&](int q, int dy) -> BStage {
+        const int cot = q / C::NCHUNK, chunk = q - cot * C::NCHUNK;
+        const unsigned char* src = w_plane0 + ((size_t)(chunk * 9 + dy * 3) * 4 * COUT + cot * 64) * 16;
+        BStage r;
+#pragma unroll
+        for (int it = 0; it < C::B_ITEMS; ++it) r.v[it] = *(const uint4*)(src + b_off[it]);
+        return r;
+    };
+    auto store_b = [&](int buf, const BStage& r) {
+#pragma unroll
+        for (int it = 0; it < C::B_ITEMS; ++it) *(uint4*)(Bbuf + buf * C::B_BUF + b_dst[it]) = r.v[it];
+    };
+    struct Frags { bf16x8 wh[4], wl[4], xh[C::MR], xl[C::MR]; };
+    auto read_frags = [&](Frags& f, const unsigned char* Ab, const unsigned char* Bb, int k3) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            f.wh[n] = __builtin_bit_cast(bf16x8, *(const uint4*)(Bb + (k3 * 256 + n * 16) * 16));
+            f.wl[n] = __builtin_bit_cast(bf16x8, *(const uint4*)(Bb + C::B_PLANE + (k3 * 256 + n * 16) * 16));
+        }
 #pragma unroll
         for (int m = 0; m < C::MR; ++m) {
-            const int oy = ty0 + wave * C::MR + m;
-            if (oy >= a.Hout) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ox = tx0 + kg * 4 + r;
-                if (ox >= a.Wout) continue;
-                const float v = acc[m][n][r] + bias;
-                if (OUT_STATE) {
-                    float* p = out_img + zc_offset(vst_level_of_channels(COUT), oy, ox, a.Wq) + co;
-                    *p = *p + a.sign * v;
-                } else {
-                    out_img[((size_t)oy * a.Wout + ox) * COUT + co] = v > 0.f ? v : 0.f;
-                }
-            }
+            f.xh[m] = __builtin_bit_cast(bf16x8, *(const uint4*)(Ab + (m * C::IW + k3) * 16));
+            f.xl[m] = __builtin_bit_cast(bf16x8, *(const uint4*)(Ab + C::A_PLANE + (m * C::IW + k3) * 16));
         }
+    };
+
+    constexpr int Q = C::NCOT * C::NCHUNK;                  // (output slice, chunk) pairs; stage s = 3q + dy
+    static_assert(Q % 2 == 0, "stage parity is static only for an even number of (slice, chunk) pairs");
+    // ---- prologue: chunk 0 activations + stage 0 weights land in LDS; stage 1 weights and the first third of
+    //      chunk 1 stay in registers (they are written to LDS during stage 0).  Register set[s&1] is loaded during
+    //      stage s and stored during stage s+1.
+    BStage rb[2];
+    APart ra[2];
+    {
+        const BStage rb0 = load_b(0, 0);
+        APart r0, r1, r2;
+        LOAD_A(r0, 0, 0); LOAD_A(r1, 0, 1); LOAD_A(r2, 0, 2);
+        rb[1] = load_b(0, 1);
+        if (C::NCHUNK > 1) LOAD_A(ra[1], 1, 0);
+        STORE_A(0, 0, r0); STORE_A(0, 1, r1); STORE_A(0, 2, r2);
+        store_b(0, rb0);
     }
+    __syncthreads();
+
+    f32x4 acc[C::MR][4];
+#pragma unroll
+    for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int slot_base = (wave * C::MR) * C::IW + lrow;
+    const int oy0 = ty0 + wave * C::MR;
+    float4 bias[4], old[C::MR][4];
+    const bool full_tile = ty0 + 16 <= a.Hout && tx0 + 16 <= a.Wout;    // uniform: interior tiles skip all predicates
+
+#pragma unroll 1
+    for (int q0 = 0; q0 < Q; q0 += 2) {
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const int q = q0 + qq;
+        const int cot = q / C::NCHUNK, chunk = q - cot * C::NCHUNK;
+        const bool last_chunk = chunk == C::NCHUNK - 1;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int s = q * 3 + dy;
+            const int cur = (qq * 3 + dy) & 1;            // compile-time parity of s
+            // ---- issue the loads that are two stages ahead (consumed from registers during the NEXT stage) ----
+            {   // weights of stage s+2
+                const int q2 = dy == 0 ? q : q + 1, dy2 = (dy + 2) % 3;
+                if (q2 < Q) rb[cur] = load_b(q2, dy2);
+                // activations stored during stage s+1 = (qn, dyn): part dyn of chunk(qn)+1 (first output slice only)
+                const int qn = dy == 2 ? q + 1 : q, dyn = (dy + 1) % 3;
+                if (qn < C::NCHUNK - 1) LOAD_A(ra[cur], qn + 1, dyn);
+            }
+            if (dy == 0 && chunk == 0) load_bias<COUT, 4>(a, cot * 64 + 4 * kg, bias);
+            if (OUT_STATE && dy == 2 && last_chunk) {     // old state values of this output slice, used after the MFMAs
+                if (full_tile) load_old<COUT, C::MR, 4, true>(a, out_img, oy0, tx0 + lrow, cot * 64 + 4 * kg, old);
+                else load_old<COUT, C::MR, 4, false>(a, out_img, oy0, tx0 + lrow, cot * 64 + 4 * kg, old);
+            }
+
+            // ---- land what was loaded one stage ago in the buffers of stage s+1 (free since the last barrier) -------
+            if (s + 1 < 3 * Q) store_b((s + 1) & 1, rb[cur ^ 1]);
+            if (q < C::NCHUNK - 1) STORE_A((chunk + 1) & 1, dy, ra[cur ^ 1]);
+
+            // ---- 3 k-steps of MFMAs on the current buffers; fragments are double-buffered in registers: the reads
+            //      of k-step k+1 are issued before the MFMAs of k-step k --------------------------------------------
+            const unsigned char* Ab = Abuf + (chunk & 1) * C::A_BUF + (kg * C::NSLOT + slot_base + dy * C::IW) * 16;
+            const unsigned char* Bb = Bbuf + (s & 1) * C::B_BUF + (kg * 64 + lrow) * 16;
+            Frags fr[2];
+            read_frags(fr[0], Ab, Bb, 0);
+#pragma unroll
+            for (int k3 = 0; k3 < 3; ++k3) {
+                __builtin_amdgcn_sched_barrier(0);            // reads of k-step k3+1 stay ahead of the MFMAs of k3
+                if (k3 < 2) read_frags(fr[(k3 + 1) & 1], Ab, Bb, k3 + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const Frags& f = fr[k3 & 1];
+#pragma unroll
+                for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) { MFMA3(acc[m][n], f.wh[n], f.wl[n], f.xh[m], f.xl[m]); }
+            }
+
+            // ---- output tile of this 64-channel slice ------------------------------------------------------------
+            if (dy == 2 && last_chunk) {
+                if (full_tile) store_tile<COUT, OUT_STATE, C::MR, 4, true>(a, out_img, oy0, tx0 + lrow, cot * 64 + 4 * kg, acc, bias, old);
+                else store_tile<COUT, OUT_STATE, C::MR, 4, false>(a, out_img, oy0, tx0 + lrow, cot * 64 + 4 * kg, acc, bias, old);
+#pragma unroll
+                for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            __syncthreads();
+        }
+      }
+    }
+#undef LOAD_A
+#undef STORE_A
 }
 
 // Diagnostic fp32 direct convolution (VST_PREC_FP32): one thread per (pixel, co), plain FMA chain.
@@ -284,18 +525,30 @@ static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) 
         return VST_OK;
     }
     if (precision != VST_PREC_BF16X3) return VST_E_MODE;
-    using C = ConvCfg<CIN, COUT, STRIDE>;
-    auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, IN_STATE, OUT_STATE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    const dim3 grid((a.Wout + C::TW - 1) / C::TW, (a.Hout + C::TH - 1) / C::TH, B * C::NCOT);
     const bool timed = g_prof_kernel == VST_KERNEL_ID(CIN, COUT, STRIDE) && g_prof_count < g_prof_cap;
     if (timed) (void)hipEventRecord(g_prof_ev[2 * g_prof_count], st);
-    kern<<<grid, 256, C::LDS_BYTES, st>>>(a);
+    if constexpr (CIN >= 64 && COUT >= 64 && STRIDE == 1) {
+        using C = PipeCfg<CIN, COUT>;
+        auto kern = conv_pipe_kernel<CIN, COUT, IN_STATE, OUT_STATE>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        kern<<<dim3((a.Wout + 15) / 16, (a.Hout + 15) / 16, B), C::NTHR, C::LDS_BYTES, st>>>(a);
+    } else {
+        using C = ConvCfg<CIN, COUT, STRIDE>;
+        auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, IN_STATE, OUT_STATE>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        const dim3 grid((a.Wout + C::TW - 1) / C::TW, (a.Hout + C::TH - 1) / C::TH, B * C::NCOT);
+        kern<<<grid, 256, C::LDS_BYTES, st>>>(a);
+    }
     if (timed) { (void)hipEventRecord(g_prof_ev[2 * g_prof_count + 1], st); ++g_prof_count; }
     VST_RETURN_IF_LAUNCH_FAILED();
     return VST_OK;

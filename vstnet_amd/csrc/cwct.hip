@@ -96,43 +96,56 @@ __global__ __launch_bounds__(256) void cwct_stats_partial_kernel(const float* __
     }
 }
 
-__global__ __launch_bounds__(256) void cwct_stats_final_kernel(const float* __restrict__ partial, int G, int N,
-                                                               double* __restrict__ stats) {
-    __shared__ double mu[128];
-    __shared__ double ntot_s;
-    const int tid = threadIdx.x;
+// Combine the per-workgroup records in fp64 (Chan et al. pairwise update).  Both kernels give 16 threads
+// to every output (a channel mean / a covariance entry), each summing G/16 records, then reduce in LDS.
+__global__ __launch_bounds__(256) void cwct_stats_mean_kernel(const float* __restrict__ partial, int G, int N,
+                                                              double* __restrict__ stats) {
+    __shared__ double sacc[16][17], snt[16][17];
+    const int cl = threadIdx.x & 15, gl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     const size_t PS = cwct_partial_stride(N);
-    if (tid < N) {
-        double acc = 0.0, nt = 0.0;
-        for (int g = 0; g < G; ++g) {
-            const float* rec = partial + (size_t)g * PS;
-            const double n = rec[0];
-            nt += n;
-            acc += n * (double)rec[4 + tid] + (double)rec[4 + N + tid];
-        }
-        mu[tid] = nt > 0.0 ? acc / nt : 0.0;
-        if (tid == 0) ntot_s = nt;
+    double acc = 0.0, nt = 0.0;
+    for (int g = gl; g < G; g += 16) {
+        const float* rec = partial + (size_t)g * PS;
+        const double n = rec[0];
+        nt += n;
+        acc += n * (double)rec[4 + c] + (double)rec[4 + N + c];
     }
+    sacc[gl][cl] = acc; snt[gl][cl] = nt;
     __syncthreads();
-    const double ntot = ntot_s;
-    if (blockIdx.x == 0) {
-        if (tid == 0) stats[0] = ntot;
-        if (tid < N) stats[1 + tid] = mu[tid];
+    if (gl == 0) {
+        double a2 = 0.0, n2 = 0.0;
+        for (int k = 0; k < 16; ++k) { a2 += sacc[k][cl]; n2 += snt[k][cl]; }
+        stats[1 + c] = n2 > 0.0 ? a2 / n2 : 0.0;
+        if (c == 0) stats[0] = n2;
     }
-    const int e = blockIdx.x * 256 + tid;
-    if (e < N * N) {
-        const int i = e / N, j = e - i * N;
-        double m2 = 0.0;
-        for (int g = 0; g < G; ++g) {
-            const float* rec = partial + (size_t)g * PS;
-            const double n = rec[0];
-            if (n <= 0.0) continue;
+}
+
+__global__ __launch_bounds__(256) void cwct_stats_cov_kernel(const float* __restrict__ partial, int G, int N,
+                                                             double* __restrict__ stats) {
+    __shared__ double sm2[16][17];
+    const int el = threadIdx.x & 15, gl = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    const int i = e / N, j = e - i * N;
+    const size_t PS = cwct_partial_stride(N);
+    const double mu_i = stats[1 + i], mu_j = stats[1 + j];
+    double m2 = 0.0;
+    for (int g = gl; g < G; g += 16) {
+        const float* rec = partial + (size_t)g * PS;
+        const double n = rec[0];
+        if (n > 0.0) {
             const double ai = rec[4 + N + i], aj = rec[4 + N + j];
-            const double di = (double)rec[4 + i] + ai / n - mu[i];
-            const double dj = (double)rec[4 + j] + aj / n - mu[j];
+            const double di = (double)rec[4 + i] + ai / n - mu_i;
+            const double dj = (double)rec[4 + j] + aj / n - mu_j;
             m2 += (double)rec[4 + 2 * N + e] - ai * aj / n + n * di * dj;
         }
-        stats[1 + N + e] = m2 / (ntot - 1.0);
+    }
+    sm2[gl][el] = m2;
+    __syncthreads();
+    if (gl == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += sm2[k][el];
+        stats[1 + N + e] = t / (stats[0] - 1.0);
     }
 }
 
@@ -338,7 +351,9 @@ int vst_cwct_stats(const float* x, int N, long L, const uint8_t* mask, int label
         default: cwct_stats_partial_kernel<8><<<G, 256, 0, st>>>(x, L, mask, label, partial, per); break;
     }
     VST_RETURN_IF_LAUNCH_FAILED();
-    cwct_stats_final_kernel<<<(N * N + 255) / 256, 256, 0, st>>>(partial, G, N, stats);
+    cwct_stats_mean_kernel<<<N / 16, 256, 0, st>>>(partial, G, N, stats);
+    VST_RETURN_IF_LAUNCH_FAILED();
+    cwct_stats_cov_kernel<<<N * N / 16, 256, 0, st>>>(partial, G, N, stats);
     VST_RETURN_IF_LAUNCH_FAILED();
     return VST_OK;
 }
