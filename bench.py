@@ -45,9 +45,8 @@ def main():
     from vstnet_amd import _lib
     from vstnet_amd.synth import synthetic_state_dict, synthetic_frames
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from vstnet_amd.sharding import dist_env, shard_range, timed_steps
+    rank, local_rank, world = dist_env()
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -65,11 +64,11 @@ def main():
     net = net.to(dev).eval()
     cw = cWCT()
 
-    # frame f of the job has seed (0, f); rank r owns frames r*fpg .. r*fpg+fpg-1 (contiguous shard)
-    first = rank * fpg
+    # frame f of the job has seed (0, f); rank r owns a contiguous shard of the world*fpg frames
+    first, last = shard_range(world * fpg, rank, world)
     import numpy as np
     frames = []
-    for f in range(first, first + fpg):
+    for f in range(first, last):
         rng = np.random.Generator(np.random.PCG64([0, f]))
         frames.append(rng.random((3, S, S), dtype=np.float32))
     content = torch.from_numpy(np.stack(frames)).to(dev)
@@ -88,23 +87,8 @@ def main():
                 z_cs = cw.transfer_with_stats(z_c, s_stats)
             return net(z_cs, forward=False)
 
-        def barrier():
-            if world > 1:
-                dist.barrier()
-
-        for _ in range(args.warmup):
-            out = step()
-        barrier(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
-        torch.cuda.synchronize(); barrier()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        assert torch.isfinite(out).all()
+        elapsed = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, world, device=dev)
+        assert torch.isfinite(step()).all()
 
         # ---- live roofline of the dominant kernel: HIP events around each of its launches ------------
         L = _lib.lib()
