@@ -289,7 +289,7 @@ struct PipeCfg {
     static constexpr int B_PLANE = 3 * 4 * 64 * 16, B_BUF = 2 * B_PLANE;      // 24576 (hi + lo, 3 k-steps x 64 channels)
     static constexpr int LDS_BYTES = 2 * A_BUF + 2 * B_BUF;                   // 135168
     static constexpr int A_PART = NPIX * 4 / 3;                               // 432 (slot, cig) items per stage
-    static constexpr int A_ITEMS = (A_PART + NTHR - 1) / NTHR;                // per thread and part
+    static constexpr int A_ITEMS = ((A_PART / 4 + 15) / 16 * 64 + NTHR - 1) / NTHR;   // per thread and part (lanes in 16-slot x 4-plane groups)
     static constexpr int B_ITEMS = 2 * 768 / NTHR;                            // uint4 per thread and stage
 };
 
@@ -323,9 +323,12 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const ConvArgs a) {
     for (int part = 0; part < 3; ++part)
 #pragma unroll
         for (int it = 0; it < C::A_ITEMS; ++it) {
+            // 16 consecutive lanes take 16 consecutive slots of ONE channel-group plane (conflict-free ds_write_b128;
+            // cig-fastest would put 4 lanes on the same banks) and together still read whole 128-byte pixel chunks
             const int j = it * C::NTHR + tid;
-            const int idx = part * C::A_PART + (j < C::A_PART ? j : C::A_PART - 1);
-            const int cig = idx & 3, slot = idx >> 2;
+            int sl = (j >> 6) * 16 + (j & 15);                       // slot within this part (108 slots per part)
+            sl = sl < C::A_PART / 4 ? sl : C::A_PART / 4 - 1;
+            const int cig = (j >> 4) & 3, slot = part * (C::A_PART / 4) + sl;
             const int iy = slot / C::IW, ix = slot - iy * C::IW;
             const int gy = reflect_clamp(ty0 - 1 + iy, a.Hin), gx = reflect_clamp(tx0 - 1 + ix, a.Win);
             const size_t off = IN_STATE ? zc_offset(vst_level_of_channels(CIN), gy, gx, a.Wq)
