@@ -647,12 +647,18 @@ int vst_block_apply(const vst_block_weights* w, int channel, int stride, int dir
 
 size_t vst_pass_workspace_bytes(int B, int H, int W) { return (size_t)B * H * W * (16 + 16 + 8) * sizeof(float); }
 
-int vst_revnet_forward(const vst_net_weights* w, const float* x, float* z, void* workspace, int B, int C_in, int H,
-                       int W, int sp_steps, int precision, void* stream) {
-    if (!w || !x || !z) return VST_E_ARG;
-    if (!workspace) return VST_E_WORKSPACE;
-    if (!vst_shape_ok(B, H, W) || C_in < 1 || C_in > 16) return VST_E_SHAPE;
-    if (sp_steps != 1 && sp_steps != 2) return VST_E_MODE;
+// Images per internal sub-batch: the reversible state + intermediates of a sub-batch (160 B/pixel) should stay in
+// the 256 MiB Infinity Cache between the 96 conv launches of a pass (measured: 8 frames of 1024x1024 in one batch
+// run 27 % slower per frame than one at a time); small images are still batched to fill the chip.
+static int pass_sub_batch(int B, int H, int W) {
+    const size_t per_img = (size_t)H * W * 160;
+    size_t nb = ((size_t)192 << 20) / per_img;
+    if (nb < 1) nb = 1;
+    return nb > (size_t)B ? B : (int)nb;
+}
+
+static int revnet_forward_chunk(const vst_net_weights* w, const float* x, float* z, void* workspace, int B, int C_in,
+                                int H, int W, int sp_steps, int precision, void* stream) {
     float* s[2];
     s[0] = (float*)workspace;
     s[1] = s[0] + (size_t)B * H * W * 16;
@@ -667,12 +673,8 @@ int vst_revnet_forward(const vst_net_weights* w, const float* x, float* z, void*
     return vst_spread(s[0], s[1], z, B, H, W, sp_steps, stream);
 }
 
-int vst_revnet_inverse(const vst_net_weights* w, const float* z, float* x, void* workspace, int B, int C_out, int H,
-                       int W, int sp_steps, int precision, void* stream) {
-    if (!w || !x || !z) return VST_E_ARG;
-    if (!workspace) return VST_E_WORKSPACE;
-    if (!vst_shape_ok(B, H, W) || C_out < 1 || C_out > 16) return VST_E_SHAPE;
-    if (sp_steps != 1 && sp_steps != 2) return VST_E_MODE;
+static int revnet_inverse_chunk(const vst_net_weights* w, const float* z, float* x, void* workspace, int B, int C_out,
+                                int H, int W, int sp_steps, int precision, void* stream) {
     float* s[2];
     s[0] = (float*)workspace;
     s[1] = s[0] + (size_t)B * H * W * 16;
@@ -685,6 +687,40 @@ int vst_revnet_inverse(const vst_net_weights* w, const float* z, float* x, void*
         if (rc) return rc;
     }
     return vst_unpack_output(s[0], x, B, C_out, H, W, stream);
+}
+
+int vst_revnet_forward(const vst_net_weights* w, const float* x, float* z, void* workspace, int B, int C_in, int H,
+                       int W, int sp_steps, int precision, void* stream) {
+    if (!w || !x || !z) return VST_E_ARG;
+    if (!workspace) return VST_E_WORKSPACE;
+    if (!vst_shape_ok(B, H, W) || C_in < 1 || C_in > 16) return VST_E_SHAPE;
+    if (sp_steps != 1 && sp_steps != 2) return VST_E_MODE;
+    const int nb = pass_sub_batch(B, H, W);
+    const size_t zimg = (size_t)32 * H * W;                 // floats per image of z in both modes
+    for (int b0 = 0; b0 < B; b0 += nb) {
+        const int n = B - b0 < nb ? B - b0 : nb;
+        const int rc = revnet_forward_chunk(w, x + (size_t)b0 * C_in * H * W, z + (size_t)b0 * zimg, workspace, n, C_in, H,
+                                            W, sp_steps, precision, stream);
+        if (rc) return rc;
+    }
+    return VST_OK;
+}
+
+int vst_revnet_inverse(const vst_net_weights* w, const float* z, float* x, void* workspace, int B, int C_out, int H,
+                       int W, int sp_steps, int precision, void* stream) {
+    if (!w || !x || !z) return VST_E_ARG;
+    if (!workspace) return VST_E_WORKSPACE;
+    if (!vst_shape_ok(B, H, W) || C_out < 1 || C_out > 16) return VST_E_SHAPE;
+    if (sp_steps != 1 && sp_steps != 2) return VST_E_MODE;
+    const int nb = pass_sub_batch(B, H, W);
+    const size_t zimg = (size_t)32 * H * W;
+    for (int b0 = 0; b0 < B; b0 += nb) {
+        const int n = B - b0 < nb ? B - b0 : nb;
+        const int rc = revnet_inverse_chunk(w, z + (size_t)b0 * zimg, x + (size_t)b0 * C_out * H * W, workspace, n, C_out,
+                                            H, W, sp_steps, precision, stream);
+        if (rc) return rc;
+    }
+    return VST_OK;
 }
 
 }  // extern "C"
