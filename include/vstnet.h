@@ -127,6 +127,10 @@ int vst_cwct_factor(const double* content_stats, const double* const* style_stat
                     float* affine, int* info, void* stream);
 int vst_cwct_apply(const float* x, float* y, int N, long L, const float* affine,
                    const uint8_t* mask, int label, void* stream);
+/* Turns a statistics record into a "prefactored" one ({-(n+1), mean, chol(cov) with jitter retries}); a style that
+ * is reused over many frames (video_transfer.py re-factors it per frame, :195-203) then costs no Cholesky in
+ * vst_cwct_factor.  `out` may alias `stats`; info = int[1] retry count. */
+int vst_cwct_prefactor(const double* stats, int N, float eps, double* out, int* info, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Measurement hook (bench.py's live roofline figure): bracket every launch of one conv kernel class

@@ -96,6 +96,104 @@ __global__ __launch_bounds__(256) void cwct_stats_partial_kernel(const float* __
     }
 }
 
+// MFMA form of the partial kernel for N in {32, 64, 128}: Q = Xs Xs^T on v_mfma_f32_32x32x2_f32 (exact fp32
+// products / accumulation, i.e. the same numerics as the FMA form, at the matrix-core rate).  A and B operand of a
+// 32x32 block are the same data (lane l: xs[32*blk + (l&31)][pixel + (l>>5)]), so NBLK fragment loads feed NBLK
+// MFMAs per wave and pixel pair.  Wave w owns row block w % NBLK and pixel group w / NBLK of the 64-pixel tile.
+template <int NBLK>
+__global__ __launch_bounds__(256) void cwct_stats_mfma_kernel(const float* __restrict__ x, long L,
+                                                              const uint8_t* __restrict__ mask, int label,
+                                                              float* __restrict__ partial, int px_per_wg) {
+    constexpr int N = 32 * NBLK, PT = 64, LD = PT + 1, PG = 4 / NBLK, PPG = PT / PG;
+    __shared__ float xs[N * LD];
+    __shared__ float vflag[PT];
+    __shared__ float sh[N];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rb = wave % NBLK, pg = wave / NBLK;
+    const long p_begin = (long)blockIdx.x * px_per_wg;
+    long p_end = p_begin + px_per_wg;
+    if (p_end > L) p_end = L;
+    for (int c = tid; c < N; c += 256) sh[c] = p_begin < L ? x[(size_t)c * L + p_begin] : 0.f;
+
+    f32x16 acc[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    float asum = 0.f, cnt = 0.f;                       // row sum of channel tid (tid < N), pixel count (all threads)
+    for (long p0 = p_begin; p0 < p_end; p0 += PT) {
+        __syncthreads();
+        if (tid < PT) {
+            const long p = p0 + tid;
+            vflag[tid] = (p < p_end && (mask == nullptr || mask[p] == label)) ? 1.f : 0.f;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < N * PT; idx += 256) {
+            const int c = idx >> 6, pl = idx & 63;
+            xs[c * LD + pl] = vflag[pl] != 0.f ? x[(size_t)c * L + p0 + pl] - sh[c] : 0.f;
+        }
+        __syncthreads();
+        if (tid < N) {
+            float sacc = 0.f;
+#pragma unroll 8
+            for (int pl = 0; pl < PT; ++pl) sacc += xs[tid * LD + pl];
+            asum += sacc;
+        }
+        if (tid == 0) {
+            float c2 = 0.f;
+            for (int pl = 0; pl < PT; ++pl) c2 += vflag[pl];
+            cnt += c2;
+        }
+        const float* base = xs + (lane & 31) * LD + pg * PPG + (lane >> 5);
+#pragma unroll 4
+        for (int t = 0; t < PPG / 2; ++t) {
+            float f[NBLK];
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) f[b] = base[b * 32 * LD + 2 * t];
+            float fa = f[0];                              // f[rb] without a runtime register index
+#pragma unroll
+            for (int b = 1; b < NBLK; ++b) fa = rb == b ? f[b] : fa;
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, f[b], acc[b], 0, 0, 0);
+        }
+    }
+    // ---- combine the pixel groups (PG > 1) through LDS, then one record per workgroup ------------------------------
+    __syncthreads();
+    float* rec = partial + (size_t)blockIdx.x * cwct_partial_stride(N);
+    if (PG > 1) {
+        // one pixel group per round adds its accumulators to group 0 through the (now idle) tile buffer:
+        // NBLK*NBLK*16*64 floats <= N*LD for N = 32 (1024 <= 2080) and N = 64 (4096 <= 4160)
+        for (int round = 1; round < PG; ++round) {
+            __syncthreads();
+            if (pg == round) {
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xs[((rb * NBLK + b) * 16 + r) * 64 + lane] = acc[b][r];
+            }
+            __syncthreads();
+            if (pg == 0) {
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[b][r] += xs[((rb * NBLK + b) * 16 + r) * 64 + lane];
+            }
+        }
+    }
+    if (tid == 0) rec[0] = cnt;
+    for (int c = tid; c < N; c += 256) rec[4 + c] = sh[c];
+    if (tid < N) rec[4 + N + tid] = asum;
+    if (pg == 0) {
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = b * 32 + (lane & 31);
+                rec[4 + 2 * N + (size_t)i * N + j] = acc[b][r];
+            }
+    }
+}
+
 // Combine the per-workgroup records in fp64 (Chan et al. pairwise update).  Both kernels give 16 threads
 // to every output (a channel mean / a covariance entry), each summing G/16 records, then reduce in LDS.
 __global__ __launch_bounds__(256) void cwct_stats_mean_kernel(const float* __restrict__ partial, int G, int N,
@@ -164,97 +262,199 @@ struct FactorArgs {
     int* info;
 };
 
-// in-place lower Cholesky of the N x N matrix A (row stride N) in LDS; returns true on failure
-__device__ bool chol_lds(float* A, int N, int tid, int* flag) {
-    for (int j = 0; j < N; ++j) {
-        __syncthreads();
-        if (tid == 0) {
-            const float d = A[j * N + j];
-            if (!(d > 0.f)) *flag = 1; else A[j * N + j] = sqrtf(d);
+// The N x N matrices live in registers, distributed 2-D cyclically over the 16 x 16 threads: thread (ti, tj)
+// owns elements (ti + 16 a, tj + 16 b), a, b < BLK = N / 16.  Column / row broadcasts go through LDS; two
+// barriers per Cholesky column, one per solve column.  fp32 arithmetic with LAPACK's failure rule (pivot <= 0
+// or NaN) so that the jitter retries of cholesky_dec (cWCT.py:111-132) trigger like the reference's.
+template <int BLK>
+__device__ __forceinline__ void fac_load(const double* stats, int tries, float eps, int ti, int tj, float (&r)[BLK][BLK]) {
+    constexpr int N = 16 * BLK;
+    const double* cov = stats + 1 + N;
+#pragma unroll
+    for (int a = 0; a < BLK; ++a)
+#pragma unroll
+        for (int b = 0; b < BLK; ++b) {
+            const int i = ti + 16 * a, k = tj + 16 * b;
+            float v = (float)cov[i * N + k];
+            if (i == k)
+                for (int t = 1; t <= tries; ++t) v = v + (float)((double)t * (double)eps);   // eps, 2 eps, ... cumulative
+            r[a][b] = v;
         }
-        __syncthreads();
-        if (*flag) return true;
-        const float piv = A[j * N + j];
-        for (int i = j + 1 + tid; i < N; i += 256) A[i * N + j] /= piv;
-        __syncthreads();
-        const int m = N - 1 - j;
-        for (int idx = tid; idx < m * m; idx += 256) {
-            const int ii = j + 1 + idx / m, kk = j + 1 + idx % m;
-            if (kk <= ii) A[ii * N + kk] -= A[ii * N + j] * A[kk * N + j];
+}
+
+template <int BLK>
+__device__ bool fac_chol(float (&r)[BLK][BLK], int ti, int tj, float* col, float* s_piv, int* s_flag) {
+    __syncthreads();
+    if (ti == 0 && tj == 0) *s_flag = 0;
+    __syncthreads();
+#pragma unroll
+    for (int jb = 0; jb < BLK; ++jb) {
+#pragma unroll 1
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = 16 * jb + jj;
+            if (ti == jj && tj == jj) {
+                const float d = r[jb][jb];
+                if (!(d > 0.f)) *s_flag = 1; else *s_piv = sqrtf(d);
+            }
+            __syncthreads();
+            if (*s_flag) return true;                       // uniform
+            const float piv = *s_piv;
+            if (tj == jj) {
+#pragma unroll
+                for (int a = jb; a < BLK; ++a) {
+                    const int i = ti + 16 * a;
+                    if (i > j) { r[a][jb] = r[a][jb] / piv; col[i] = r[a][jb]; }
+                    else if (i == j) { r[a][jb] = piv; col[i] = piv; }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int a = jb; a < BLK; ++a)
+#pragma unroll
+                for (int b = jb; b < BLK; ++b) {
+                    const int i = ti + 16 * a, k = tj + 16 * b;
+                    if (i > j && k > j && k <= i) r[a][b] -= col[i] * col[k];
+                }
         }
     }
-    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < BLK; ++a)
+#pragma unroll
+        for (int b = 0; b < BLK; ++b)
+            if (tj + 16 * b > ti + 16 * a) r[a][b] = 0.f;
     return false;
 }
 
-// Cholesky of the covariance in `stats` with the cumulative-jitter schedule of cWCT.py:115-128.
-__device__ int chol_with_jitter(const double* stats, float* A, int N, float eps, int tid, int* flag) {
-    const double* cov = stats + 1 + N;
+// lower Cholesky factor of the covariance in `stats` (or the stored factor if the record is prefactored:
+// stats[0] < 0) -> r; returns the number of jitter retries
+template <int BLK>
+__device__ int fac_factor(const double* stats, float eps, int ti, int tj, float (&r)[BLK][BLK], float* col, float* s_piv,
+                          int* s_flag) {
+    constexpr int N = 16 * BLK;
+    if (stats[0] < 0.0) {
+#pragma unroll
+        for (int a = 0; a < BLK; ++a)
+#pragma unroll
+            for (int b = 0; b < BLK; ++b) r[a][b] = (float)stats[1 + N + (ti + 16 * a) * N + tj + 16 * b];
+        return 0;
+    }
     int tries = 0;
     while (true) {
-        __syncthreads();
-        for (int idx = tid; idx < N * N; idx += 256) {
-            float v = (float)cov[idx];
-            if (idx / N == idx % N)
-                for (int t = 1; t <= tries; ++t) v = v + (float)((double)t * (double)eps);
-            A[idx] = v;
-        }
-        if (tid == 0) *flag = 0;
-        __syncthreads();
-        const bool failed = chol_lds(A, N, tid, flag);
+        fac_load<BLK>(stats, tries, eps, ti, tj, r);
+        const bool failed = fac_chol<BLK>(r, ti, tj, col, s_piv, s_flag);
         if (!failed || tries >= CWCT_MAX_TRIES) break;
         ++tries;
     }
     return tries;
 }
 
+template <int BLK>
 __global__ __launch_bounds__(256) void cwct_factor_kernel(const FactorArgs a) {
+    constexpr int N = 16 * BLK;
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
-    const int N = a.N, tid = threadIdx.x, LDT = N + 1;
-    float* A = (float*)fsm;                  // N*N      Cholesky workspace, finally Lc
-    float* T = A + N * N;                    // N*(N+1)  mixL, solved in place into T
-    double* mixmu = (double*)(T + N * LDT);  // N doubles; N*N + N*(N+1) floats is even -> 8-byte aligned
-    int* const flagp = (int*)(mixmu + N);    // all LDS lives in the dynamic region (16-byte aligned base)
+    float* Lmat = (float*)fsm;             // N*N   Lc, row-major
+    float* col = Lmat + N * N;             // N     column broadcast of the Cholesky
+    float* tcol = col + N;                 // 2*N   column broadcast of the solve (double-buffered)
+    float* s_piv = tcol + 2 * N;
+    int* s_flag = (int*)(s_piv + 1);
+    const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
 
-    for (int idx = tid; idx < N * LDT; idx += 256) T[idx] = 0.f;
-    if (tid < N) mixmu[tid] = 0.0;
-    __syncthreads();
+    float r[BLK][BLK], m[BLK][BLK];
+    double mixmu[BLK];
+#pragma unroll
+    for (int a2 = 0; a2 < BLK; ++a2) {
+        mixmu[a2] = 0.0;
+#pragma unroll
+        for (int b = 0; b < BLK; ++b) m[a2][b] = 0.f;
+    }
     for (int s = 0; s < a.n_styles; ++s) {
-        const int tries = chol_with_jitter(a.styles[s], A, N, a.eps, tid, flagp);
+        const int tries = fac_factor<BLK>(a.styles[s], a.eps, ti, tj, r, col, s_piv, s_flag);
         if (tid == 0) a.info[2 + s] = tries;
         const float al = a.alphas[s];
-        for (int idx = tid; idx < N * N; idx += 256) {
-            const int i = idx / N, j = idx - i * N;
-            if (j <= i) T[i * LDT + j] += A[idx] * al;
+#pragma unroll
+        for (int a2 = 0; a2 < BLK; ++a2) {
+            mixmu[a2] += (double)(float)a.styles[s][1 + ti + 16 * a2] * (double)al;
+#pragma unroll
+            for (int b = 0; b < BLK; ++b) m[a2][b] += r[a2][b] * al;
         }
-        if (tid < N) mixmu[tid] += (double)(float)a.styles[s][1 + tid] * (double)al;
-        __syncthreads();
     }
-    const int ctries = chol_with_jitter(a.content, A, N, a.eps, tid, flagp);
+    const int ctries = fac_factor<BLK>(a.content, a.eps, ti, tj, r, col, s_piv, s_flag);
     if (tid == 0) { a.info[0] = ctries; a.info[1] = ctries >= CWCT_MAX_TRIES; }
     if (a.alpha_c != 0.f) {
         const float ac = a.alpha_c;
-        for (int idx = tid; idx < N * N; idx += 256) {
-            const int i = idx / N, j = idx - i * N;
-            if (j <= i) T[i * LDT + j] = T[i * LDT + j] * (1.f - ac) + A[idx] * ac;
+#pragma unroll
+        for (int a2 = 0; a2 < BLK; ++a2) {
+            mixmu[a2] = mixmu[a2] * (double)(1.f - ac) + (double)(float)a.content[1 + ti + 16 * a2] * (double)ac;
+#pragma unroll
+            for (int b = 0; b < BLK; ++b) m[a2][b] = m[a2][b] * (1.f - ac) + r[a2][b] * ac;
         }
-        if (tid < N) mixmu[tid] = mixmu[tid] * (double)(1.f - ac) + (double)(float)a.content[1 + tid] * (double)ac;
     }
     __syncthreads();
-    // solve T * Lc = mixL row-wise from the last column (T lower triangular)
-    if (tid < N) {
-        float* row = T + tid * LDT;
-        for (int j = tid; j >= 0; --j) {
-            double acc = row[j];
-            for (int k = j + 1; k <= tid; ++k) acc -= (double)row[k] * (double)A[k * N + j];
-            row[j] = (float)(acc / (double)A[j * N + j]);
-        }
-        double t0 = mixmu[tid];
-        for (int j = 0; j <= tid; ++j) t0 -= (double)row[j] * a.content[1 + j];
-        a.affine[N * N + tid] = (float)t0;
-    }
+#pragma unroll
+    for (int a2 = 0; a2 < BLK; ++a2)
+#pragma unroll
+        for (int b = 0; b < BLK; ++b) Lmat[(ti + 16 * a2) * N + tj + 16 * b] = r[a2][b];
     __syncthreads();
-    for (int idx = tid; idx < N * N; idx += 256) a.affine[idx] = T[(idx / N) * LDT + idx % N];
+    // ---- solve T * Lc = mixL in place (m := T), last column first; T stays lower triangular ---------------------------
+    int par = 0;
+#pragma unroll
+    for (int jb = BLK - 1; jb >= 0; --jb) {
+#pragma unroll 1
+        for (int jj = 15; jj >= 0; --jj) {
+            const int j = 16 * jb + jj;
+            if (tj == jj) {
+                const float ljj = Lmat[j * N + j];
+#pragma unroll
+                for (int a2 = 0; a2 < BLK; ++a2) {
+                    const float t = m[a2][jb] / ljj;
+                    m[a2][jb] = t;
+                    tcol[par * N + ti + 16 * a2] = t;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int a2 = 0; a2 < BLK; ++a2)
+#pragma unroll
+                for (int b = 0; b <= jb; ++b) {
+                    const int k = tj + 16 * b;
+                    if (k < j) m[a2][b] -= tcol[par * N + ti + 16 * a2] * Lmat[j * N + k];
+                }
+            par ^= 1;
+        }
+    }
+    // ---- t0 = mix_mean - T * mean_c (reduce over the 16 threads of a row: contiguous lanes), write {T, t0} ----------
+#pragma unroll
+    for (int a2 = 0; a2 < BLK; ++a2) {
+        double part = 0.0;
+#pragma unroll
+        for (int b = 0; b < BLK; ++b) part += (double)m[a2][b] * a.content[1 + tj + 16 * b];
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) part += __shfl_xor(part, off, 16);
+        if (tj == 0) a.affine[N * N + ti + 16 * a2] = (float)(mixmu[a2] - part);
+#pragma unroll
+        for (int b = 0; b < BLK; ++b) a.affine[(ti + 16 * a2) * N + tj + 16 * b] = m[a2][b];
+    }
+}
+
+// stats {n, mean, cov} -> prefactored record {-(n+1), mean, L} so that later factor calls skip this Cholesky
+template <int BLK>
+__global__ __launch_bounds__(256) void cwct_prefactor_kernel(const double* stats, float eps, double* out, int* info) {
+    constexpr int N = 16 * BLK;
+    __shared__ float col[N];
+    __shared__ float s_piv;
+    __shared__ int s_flag;
+    const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+    float r[BLK][BLK];
+    const int tries = fac_factor<BLK>(stats, eps, ti, tj, r, col, &s_piv, &s_flag);
+    const double n = stats[0];
+    const double mean = tid < N ? stats[1 + tid] : 0.0;
+    __syncthreads();                                        // out may alias stats: every read is done
+    if (tid == 0) { out[0] = n < 0.0 ? n : -(n + 1.0); info[0] = tries; }
+    if (tid < N) out[1 + tid] = mean;
+#pragma unroll
+    for (int a = 0; a < BLK; ++a)
+#pragma unroll
+        for (int b = 0; b < BLK; ++b) out[1 + N + (ti + 16 * a) * N + tj + 16 * b] = (double)r[a][b];
 }
 
 // ================================================================================================
@@ -312,9 +512,103 @@ __global__ __launch_bounds__(256) void cwct_apply_kernel(const float* x, float* 
     }
 }
 
+// MFMA form for N in {32, 64, 128}: D[32 channels x 32 pixels] += T[32 x 2] * X[2 x 32] on v_mfma_f32_32x32x2_f32
+// (exact fp32).  T sits in LDS (row stride N+1: conflict-free column reads); the X operand is read straight from
+// global memory, coalesced along pixels: lane l holds channel 2t + (l>>5) of pixels (l&31)*PXV .. +PXV-1, i.e.
+// PXV interleaved 32-pixel sets per wave, so loads and stores are PXV floats wide.
+template <int NBLK, int PXV>
+__global__ __launch_bounds__(256) void cwct_apply_mfma_kernel(const float* x, float* y, long L,
+                                                              const float* __restrict__ affine,
+                                                              const uint8_t* __restrict__ mask, int label, long ngroups) {
+    constexpr int N = 32 * NBLK, LDT = N + 1, GP = 32 * PXV;
+    extern __shared__ __attribute__((aligned(16))) float asm_[];
+    float* Tl = asm_;
+    float* t0 = asm_ + N * LDT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid; idx < N * N; idx += 256) Tl[(idx / N) * LDT + idx % N] = affine[idx];
+    for (int idx = tid; idx < N; idx += 256) t0[idx] = affine[N * N + idx];
+    __syncthreads();
+    const int col = lane & 31, kh = lane >> 5;
+    for (long g = (long)blockIdx.x * 4 + wave; g < ngroups; g += (long)gridDim.x * 4) {
+        const long pl = g * GP + (long)col * PXV;
+        const bool inside = pl < L;                          // L % PXV == 0: the lane's PXV pixels are all in or all out
+        const long plc = inside ? pl : L - PXV;
+        bool on[PXV];
+        bool any = false, all = true;
+#pragma unroll
+        for (int q = 0; q < PXV; ++q) {
+            on[q] = inside && (mask == nullptr || mask[plc + q] == label);
+            any |= on[q]; all &= on[q];
+        }
+        if (!__any(any)) continue;                           // no pixel of this label in the wave's 32*PXV pixels
+        f32x16 acc[PXV][NBLK];
+#pragma unroll
+        for (int q = 0; q < PXV; ++q)
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][b][r] = 0.f;
+        const float* xp = x + plc + (size_t)kh * L;
+        const float* tp = Tl + col * LDT + kh;
+#pragma unroll 4
+        for (int t = 0; t < N / 2; ++t) {
+            float v[PXV];
+            if (PXV == 4) { const float4 w = *(const float4*)(xp + (size_t)2 * t * L); v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w; }
+            else if (PXV == 2) { const float2 w = *(const float2*)(xp + (size_t)2 * t * L); v[0] = w.x; v[1] = w.y; }
+            else v[0] = xp[(size_t)2 * t * L];
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) {
+                const float av = tp[b * 32 * LDT + 2 * t];
+#pragma unroll
+                for (int q = 0; q < PXV; ++q) acc[q][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, v[q], acc[q][b], 0, 0, 0);
+            }
+        }
+        if (!any) continue;
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = b * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const float bias = t0[i];
+                float* dst = y + (size_t)i * L + pl;
+                if (PXV == 4 && all) *(float4*)dst = make_float4(acc[0][b][r] + bias, acc[1][b][r] + bias, acc[2][b][r] + bias, acc[3][b][r] + bias);
+                else if (PXV == 2 && all) *(float2*)dst = make_float2(acc[0][b][r] + bias, acc[1][b][r] + bias);
+                else {
+#pragma unroll
+                    for (int q = 0; q < PXV; ++q) if (on[q]) dst[q] = acc[q][b][r] + bias;
+                }
+            }
+    }
+}
+
+template <int NBLK, int PXV>
+static int launch_apply_mfma(const float* x, float* y, long L, const float* affine, const uint8_t* mask, int label,
+                             hipStream_t st) {
+    constexpr int N = 32 * NBLK;
+    const long ngroups = (L + 32 * PXV - 1) / (32 * PXV);
+    long wgs = (ngroups + 3) / 4;
+    if (wgs > 2048) wgs = 2048;
+    const size_t lds = ((size_t)N * (N + 1) + N) * sizeof(float);
+    auto kern = cwct_apply_mfma_kernel<NBLK, PXV>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    kern<<<dim3((unsigned)wgs), 256, lds, st>>>(x, y, L, affine, mask, label, ngroups);
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
 template <int N>
 static int launch_apply(const float* x, float* y, long L, const float* affine, const uint8_t* mask, int label,
                         hipStream_t st) {
+    if (N >= 32) {                                           // matrix-core path (needs vector-aligned rows)
+        constexpr int PXM = N == 32 ? 4 : 2;
+        if ((L % PXM) == 0 && L >= PXM && (((uintptr_t)x | (uintptr_t)y) % (4 * PXM)) == 0)
+            return launch_apply_mfma<(N >= 32 ? N / 32 : 1), PXM>(x, y, L, affine, mask, label, st);
+    }
     constexpr int PXV = N <= 32 ? 4 : (N <= 64 ? 2 : 1);
     const bool vec = (L % PXV) == 0 && (((uintptr_t)x | (uintptr_t)y) % (4 * PXV)) == 0;
     if (vec && PXV > 1) {
@@ -346,9 +640,9 @@ int vst_cwct_stats(const float* x, int N, long L, const uint8_t* mask, int label
     float* partial = (float*)workspace;
     switch (N) {
         case 16: cwct_stats_partial_kernel<1><<<G, 256, 0, st>>>(x, L, mask, label, partial, per); break;
-        case 32: cwct_stats_partial_kernel<2><<<G, 256, 0, st>>>(x, L, mask, label, partial, per); break;
-        case 64: cwct_stats_partial_kernel<4><<<G, 256, 0, st>>>(x, L, mask, label, partial, per); break;
-        default: cwct_stats_partial_kernel<8><<<G, 256, 0, st>>>(x, L, mask, label, partial, per); break;
+        case 32: cwct_stats_mfma_kernel<1><<<G, 256, 0, st>>>(x, L, mask, label, partial, per); break;
+        case 64: cwct_stats_mfma_kernel<2><<<G, 256, 0, st>>>(x, L, mask, label, partial, per); break;
+        default: cwct_stats_mfma_kernel<4><<<G, 256, 0, st>>>(x, L, mask, label, partial, per); break;
     }
     VST_RETURN_IF_LAUNCH_FAILED();
     cwct_stats_mean_kernel<<<N / 16, 256, 0, st>>>(partial, G, N, stats);
@@ -372,15 +666,35 @@ int vst_cwct_factor(const double* content_stats, const double* const* style_stat
         a.alphas[i] = alphas_host[i];
     }
     a.n_styles = n_styles; a.alpha_c = alpha_c; a.eps = eps; a.N = N; a.affine = affine; a.info = info;
-    const size_t lds = (size_t)N * N * 4 + (size_t)N * (N + 1) * 4 + (size_t)N * 8 + 16;
+    const size_t lds = (size_t)N * N * 4 + (size_t)3 * N * 4 + 16;
+    hipStream_t st = (hipStream_t)stream;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)cwct_factor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           150 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)cwct_factor_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           80 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    cwct_factor_kernel<<<1, 256, lds, (hipStream_t)stream>>>(a);
+    switch (N) {
+        case 16: cwct_factor_kernel<1><<<1, 256, lds, st>>>(a); break;
+        case 32: cwct_factor_kernel<2><<<1, 256, lds, st>>>(a); break;
+        case 64: cwct_factor_kernel<4><<<1, 256, lds, st>>>(a); break;
+        default: cwct_factor_kernel<8><<<1, 256, lds, st>>>(a); break;
+    }
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
+int vst_cwct_prefactor(const double* stats, int N, float eps, double* out, int* info, void* stream) {
+    if (!stats || !out || !info) return VST_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (N) {
+        case 16: cwct_prefactor_kernel<1><<<1, 256, 0, st>>>(stats, eps, out, info); break;
+        case 32: cwct_prefactor_kernel<2><<<1, 256, 0, st>>>(stats, eps, out, info); break;
+        case 64: cwct_prefactor_kernel<4><<<1, 256, 0, st>>>(stats, eps, out, info); break;
+        case 128: cwct_prefactor_kernel<8><<<1, 256, 0, st>>>(stats, eps, out, info); break;
+        default: return VST_E_SHAPE;
+    }
     VST_RETURN_IF_LAUNCH_FAILED();
     return VST_OK;
 }

@@ -134,7 +134,15 @@ class cWCT(nn.Module):
         compute this once per style and call transfer_with_stats per frame."""
         B, N = style_feat.shape[:2]
         s = self._prep(style_feat).reshape(B, N, -1)
-        return [self.stats(s[b]) for b in range(B)]
+        out = []
+        for b in range(B):
+            st = self.stats(s[b])
+            info = torch.zeros(1, dtype=torch.int32, device=st.device)
+            with torch.cuda.device(st.device):       # Cholesky once per style, in place
+                _lib.check(_lib.lib().vst_cwct_prefactor(_ptr(st), N, float(self.eps), _ptr(st), _ptr(info), _stream_ptr()),
+                           "vst_cwct_prefactor")
+            out.append(st)
+        return out
 
     def transfer_with_stats(self, content_feat, style_stats, alpha_c=0.0):
         """transfer(content, style) with the style side given as style_stats(style) (len B or 1)."""
