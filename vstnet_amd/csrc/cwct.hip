@@ -22,6 +22,7 @@ __host__ __device__ inline size_t cwct_partial_stride(int N) { return (size_t)N 
 
 static inline int cwct_stats_groups(long L, int* px_per_wg) {
     long per = 2048;
+    while (per > 512 && L / per < 256) per >>= 1;          // enough workgroups to fill the chip on small codes
     long g = (L + per - 1) / per;
     if (g > 1024) { g = 1024; per = ((L + g - 1) / g + 63) / 64 * 64; g = (L + per - 1) / per; }
     *px_per_wg = (int)per;
@@ -100,13 +101,13 @@ __global__ __launch_bounds__(256) void cwct_stats_partial_kernel(const float* __
 // products / accumulation, i.e. the same numerics as the FMA form, at the matrix-core rate).  A and B operand of a
 // 32x32 block are the same data (lane l: xs[32*blk + (l&31)][pixel + (l>>5)]), so NBLK fragment loads feed NBLK
 // MFMAs per wave and pixel pair.  Wave w owns row block w % NBLK and pixel group w / NBLK of the 64-pixel tile.
-template <int NBLK>
+template <int NBLK, bool VEC>
 __global__ __launch_bounds__(256) void cwct_stats_mfma_kernel(const float* __restrict__ x, long L,
                                                               const uint8_t* __restrict__ mask, int label,
                                                               float* __restrict__ partial, int px_per_wg) {
     constexpr int N = 32 * NBLK, PT = 64, LD = PT + 1, PG = 4 / NBLK, PPG = PT / PG;
+    constexpr int NV = N * PT / 4 / 256;                 // float4 groups per thread and tile (channel c = e>>4, pixels 4*(e&15)..)
     __shared__ float xs[N * LD];
-    __shared__ float vflag[PT];
     __shared__ float sh[N];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rb = wave % NBLK, pg = wave / NBLK;
@@ -115,34 +116,67 @@ __global__ __launch_bounds__(256) void cwct_stats_mfma_kernel(const float* __res
     if (p_end > L) p_end = L;
     for (int c = tid; c < N; c += 256) sh[c] = p_begin < L ? x[(size_t)c * L + p_begin] : 0.f;
 
+    // tile prefetch registers: values and per-pixel validity bits of this thread's float4 groups
+    float4 pv[NV];
+    unsigned pm[NV];
+    auto prefetch = [&](long p0) {
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int e = it * 256 + tid, c = e >> 4;
+            const long p = p0 + 4 * (e & 15);
+            unsigned m = 0;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (VEC) {
+                if (p < p_end) {                          // p_end, L and p are multiples of 4 here
+                    v = *(const float4*)(x + (size_t)c * L + p);
+                    m = 0xf;
+                    if (mask != nullptr) {
+                        const uchar4 mk = *(const uchar4*)(mask + p);
+                        m = (mk.x == label) | ((mk.y == label) << 1) | ((mk.z == label) << 2) | ((mk.w == label) << 3);
+                    }
+                }
+            } else {
+                float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (p + q < p_end) {
+                        t[q] = x[(size_t)c * L + p + q];
+                        m |= (mask == nullptr || mask[p + q] == label) << q;
+                    }
+                v = make_float4(t[0], t[1], t[2], t[3]);
+            }
+            pv[it] = v; pm[it] = m;
+        }
+    };
+
     f32x16 acc[NBLK];
 #pragma unroll
     for (int b = 0; b < NBLK; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-    float asum = 0.f, cnt = 0.f;                       // row sum of channel tid (tid < N), pixel count (all threads)
+    float asum = 0.f, cnt = 0.f;                       // row sum of channel tid (tid < N); pixel count (channel-0 owners)
+    prefetch(p_begin);
     for (long p0 = p_begin; p0 < p_end; p0 += PT) {
-        __syncthreads();
-        if (tid < PT) {
-            const long p = p0 + tid;
-            vflag[tid] = (p < p_end && (mask == nullptr || mask[p] == label)) ? 1.f : 0.f;
+        __syncthreads();                               // previous tile's MFMAs are done with xs
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int e = it * 256 + tid, c = e >> 4, pl = 4 * (e & 15);
+            const float s0 = sh[c];
+            const unsigned m = pm[it];
+            float* d = xs + c * LD + pl;
+            d[0] = (m & 1) ? pv[it].x - s0 : 0.f;
+            d[1] = (m & 2) ? pv[it].y - s0 : 0.f;
+            d[2] = (m & 4) ? pv[it].z - s0 : 0.f;
+            d[3] = (m & 8) ? pv[it].w - s0 : 0.f;
+            if (c == 0) cnt += (float)__popc(m);
         }
         __syncthreads();
-        for (int idx = tid; idx < N * PT; idx += 256) {
-            const int c = idx >> 6, pl = idx & 63;
-            xs[c * LD + pl] = vflag[pl] != 0.f ? x[(size_t)c * L + p0 + pl] - sh[c] : 0.f;
-        }
-        __syncthreads();
+        if (p0 + PT < p_end) prefetch(p0 + PT);        // in flight during the row sums and MFMAs below
         if (tid < N) {
             float sacc = 0.f;
 #pragma unroll 8
             for (int pl = 0; pl < PT; ++pl) sacc += xs[tid * LD + pl];
             asum += sacc;
-        }
-        if (tid == 0) {
-            float c2 = 0.f;
-            for (int pl = 0; pl < PT; ++pl) c2 += vflag[pl];
-            cnt += c2;
         }
         const float* base = xs + (lane & 31) * LD + pg * PPG + (lane >> 5);
 #pragma unroll 4
@@ -158,7 +192,6 @@ __global__ __launch_bounds__(256) void cwct_stats_mfma_kernel(const float* __res
         }
     }
     // ---- combine the pixel groups (PG > 1) through LDS, then one record per workgroup ------------------------------
-    __syncthreads();
     float* rec = partial + (size_t)blockIdx.x * cwct_partial_stride(N);
     if (PG > 1) {
         // one pixel group per round adds its accumulators to group 0 through the (now idle) tile buffer:
@@ -180,7 +213,15 @@ __global__ __launch_bounds__(256) void cwct_stats_mfma_kernel(const float* __res
             }
         }
     }
-    if (tid == 0) rec[0] = cnt;
+    // pixel count: the 16 threads that stage channel 0 (e>>4 == 0 <=> it == 0, tid < 16) each counted their 4 pixels
+    __syncthreads();
+    if (tid < 16) xs[tid] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        float c2 = 0.f;
+        for (int k = 0; k < 16; ++k) c2 += xs[k];
+        rec[0] = c2;
+    }
     for (int c = tid; c < N; c += 256) rec[4 + c] = sh[c];
     if (tid < N) rec[4 + N + tid] = asum;
     if (pg == 0) {
@@ -638,11 +679,18 @@ int vst_cwct_stats(const float* x, int N, long L, const uint8_t* mask, int label
     int per;
     const int G = cwct_stats_groups(L, &per);
     float* partial = (float*)workspace;
+    const bool vec = (L % 4) == 0 && ((uintptr_t)x % 16) == 0 && (mask == nullptr || ((uintptr_t)mask % 4) == 0);
     switch (N) {
         case 16: cwct_stats_partial_kernel<1><<<G, 256, 0, st>>>(x, L, mask, label, partial, per); break;
-        case 32: cwct_stats_mfma_kernel<1><<<G, 256, 0, st>>>(x, L, mask, label, partial, per); break;
-        case 64: cwct_stats_mfma_kernel<2><<<G, 256, 0, st>>>(x, L, mask, label, partial, per); break;
-        default: cwct_stats_mfma_kernel<4><<<G, 256, 0, st>>>(x, L, mask, label, partial, per); break;
+        case 32: if (vec) cwct_stats_mfma_kernel<1, true><<<G, 256, 0, st>>>(x, L, mask, label, partial, per);
+                 else cwct_stats_mfma_kernel<1, false><<<G, 256, 0, st>>>(x, L, mask, label, partial, per);
+                 break;
+        case 64: if (vec) cwct_stats_mfma_kernel<2, true><<<G, 256, 0, st>>>(x, L, mask, label, partial, per);
+                 else cwct_stats_mfma_kernel<2, false><<<G, 256, 0, st>>>(x, L, mask, label, partial, per);
+                 break;
+        default: if (vec) cwct_stats_mfma_kernel<4, true><<<G, 256, 0, st>>>(x, L, mask, label, partial, per);
+                 else cwct_stats_mfma_kernel<4, false><<<G, 256, 0, st>>>(x, L, mask, label, partial, per);
+                 break;
     }
     VST_RETURN_IF_LAUNCH_FAILED();
     cwct_stats_mean_kernel<<<N / 16, 256, 0, st>>>(partial, G, N, stats);
