@@ -103,6 +103,14 @@ def main():
         alg_flops = 2.0 * 9 * cin * cout * px        # fp32-equivalent conv flops (the split executes 3x as bf16 MFMA)
         achieved_tf = alg_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
 
+    # HBM bytes per launch of that kernel from the committed PMC summary (separate rocprofv3 --pmc passes of this same
+    # command; FETCH_SIZE corrected x2 for gfx950) — only valid for the workload it was taken on
+    traffic = None
+    pmc_path = os.path.join(REPO, "profiles", "r01_pmc_hbm_traffic.json")
+    if os.path.exists(pmc_path) and S == 1024 and fpg == 1 and args.mode == "photo":
+        k = json.load(open(pmc_path))["kernels"].get(f"void conv_pipe_kernel<{cin}, {cout}, true, false>(ConvArgs)")
+        traffic = k["hbm_bytes_per_launch"] if k else None
+
     frames_total = world * fpg * args.steps
     ms_per_step = elapsed / args.steps * 1e3
     value = frames_total / elapsed
@@ -120,9 +128,9 @@ def main():
                    f"forward + cWCT ({'style re-encoded per frame' if args.recompute_style else 'style statistics cached'})"
                    " + RevResNet inverse", "frames_per_gpu": fpg, "sharding": f"{world} ranks x {fpg} frame(s), no collective",
                    "weights": "synthetic seed 1234"},
-        "roofline": {"kernel": f"conv_mfma_kernel<{cin},{cout},1> (stage-3 conv.1)", "bound": "mfma",
+        "roofline": {"kernel": f"conv_pipe_kernel<{cin},{cout}> (stage-3 / channel_reduction conv.1)", "bound": "mfma",
                      "achieved": round(achieved_tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved_tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved_tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                      "avg_launch_ms": round(avg_ms, 5), "launches_timed": n_launch.value,
                      "note": "achieved counts algorithmic fp32 conv flops; the bf16x3 split issues 3x that on the MFMA pipe"},
         "frame_hbm_roofline": {"bound": "hbm", "algorithmic_bytes_per_frame": frame_bytes,
