@@ -78,6 +78,10 @@ typedef struct vst_net_weights {
 int vst_pack_input(const float* x, float* s1, float* s2, int B, int C, int H, int W, void* stream);
 /* s1 -> x[B,C,H,W]: merge + inj_pad.inverse, RevResNet.py:235-237 */
 int vst_unpack_output(const float* s1, float* x, int B, int C, int H, int W, void* stream);
+/* uint8 frame edge: frames_hwc[B,H,W,3] -> s1/s2 with ToTensor scaling (u8/255, image_transfer.py:167)
+ * and back with mul(255).clamp(0,255).byte() truncation (image_transfer.py:217-218) */
+int vst_pack_input_u8(const uint8_t* frames_hwc, float* s1, float* s2, int B, int H, int W, void* stream);
+int vst_unpack_output_u8(const float* s1, uint8_t* frames_hwc, int B, int H, int W, void* stream);
 /* merge + "spread" (unsqueeze x sp_steps), RevResNet.py:139-144 -> z[B,32,H,W] (sp=2) or [B,128,H/2,W/2] (sp=1) */
 int vst_spread(const float* s1, const float* s2, float* z, int B, int H, int W, int sp_steps, void* stream);
 /* inverse of vst_spread: squeeze x sp_steps + split, RevResNet.py:148-154 */
@@ -102,6 +106,12 @@ int vst_revnet_forward(const vst_net_weights* w, const float* x, float* z, void*
                        int B, int C_in, int H, int W, int sp_steps, int precision, void* stream);
 int vst_revnet_inverse(const vst_net_weights* w, const float* z, float* x, void* workspace,
                        int B, int C_out, int H, int W, int sp_steps, int precision, void* stream);
+
+/* the same passes with the uint8 HWC frame edge fused into the boundary kernels (video_transfer.py:188,210-214) */
+int vst_revnet_forward_u8(const vst_net_weights* w, const uint8_t* frames_hwc, float* z, void* workspace,
+                          int B, int H, int W, int sp_steps, int precision, void* stream);
+int vst_revnet_inverse_u8(const vst_net_weights* w, const float* z, uint8_t* frames_hwc, void* workspace,
+                          int B, int H, int W, int sp_steps, int precision, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * cWCT (C-1..C-6; models/cWCT.py).  Feature matrices are x[N][L] fp32 row-major (one NCHW image:

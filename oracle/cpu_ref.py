@@ -282,3 +282,26 @@ def stylize(content, style, sd, sp_steps=2, cmask=None, smask=None, alpha_c=None
 def to_uint8(img):
     """image_transfer.py:217-218 — mul(255).clamp(0,255).byte() (truncation), NCHW -> NHWC."""
     return img.mul(255).clamp(0, 255).byte().permute(0, 2, 3, 1).contiguous()
+
+
+# --------------------------------------------------------------------------- host helpers of the scripts (H-1 edge)
+def colors_to_labels_loop(arr):
+    """utils/utils.py:105-136 restated as the reference's per-pixel loop (small images only): exact colour match,
+    else the nearest colour in L1; on a tie the reference's branch raises inside try/except, keeping the first."""
+    color_dict = {(0, 0, 255): 3, (0, 255, 0): 2, (0, 0, 0): 0, (255, 255, 255): 1, (255, 0, 0): 4, (255, 255, 0): 5,
+                  (128, 128, 128): 6, (0, 255, 255): 7, (255, 0, 255): 8}
+    arr = np.asarray(arr)
+    out = np.zeros(arr.shape[:-1])
+    for x in range(arr.shape[0]):
+        for y in range(arr.shape[1]):
+            px = tuple(int(v) for v in arr[x, y, :])
+            if px in color_dict:
+                out[x, y] = color_dict[px]
+                continue
+            best, best_d = 0, 99999
+            for key, val in color_dict.items():
+                d = int(np.sum(np.abs(np.asarray(key) - arr[x, y, :].astype(np.int64))))
+                if d < best_d:
+                    best_d, best = d, val
+            out[x, y] = best
+    return out.astype(np.uint8)

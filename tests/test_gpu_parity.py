@@ -6,6 +6,7 @@ both as rel-L2 and as max|d|/max|ref|.  The bf16x3 split-precision convs land ne
 asserts below use tighter budgets where the case allows, to catch regressions early.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -325,3 +326,75 @@ def test_full_size_properties_1024():
     # 4. stylised frame is finite and decodes
     sty = net(zcs, forward=False)
     assert torch.isfinite(sty).all() and sty.shape == xc.shape
+
+
+# ------------------------------------------------------------------------------------------- uint8 frame edge (8(f) rank 1)
+def test_uint8_frame_edge():
+    """forward_u8 == forward(ToTensor(frame)); inverse_u8 == mul(255).clamp(0,255).byte() of inverse, bit for bit."""
+    net, sd, sp = make_net("photo")
+    g = torch.Generator().manual_seed(5)
+    frames = torch.randint(0, 256, (2, 40, 72, 3), dtype=torch.uint8, generator=g)
+    x = frames.permute(0, 3, 1, 2).float().div(255)               # transforms.ToTensor
+    z8 = net.forward_u8(frames.cuda())
+    assert torch.equal(z8, net(x.cuda()))
+    with torch.no_grad():
+        assert_close(z8, cpu_ref.revnet_forward(x, sd, sp), TIGHT, "forward_u8 vs oracle")
+    zp = z8 * 1.7 - 0.2                                            # push some outputs outside [0,1] to hit the clamp
+    y = net(zp, forward=False)
+    u8 = net.inverse_u8(zp)
+    assert u8.dtype == torch.uint8 and tuple(u8.shape) == (2, 40, 72, 3)
+    assert torch.equal(u8.cpu(), cpu_ref.to_uint8(y.cpu()))
+    assert int((u8 == 0).sum()) > 0 and int((u8 == 255).sum()) > 0
+    with pytest.raises(RuntimeError):
+        net.forward_u8(frames.cuda().float())
+
+
+# ------------------------------------------------------------------------------------------- drop-in scripts (8(f) rank 2)
+def _png(path, h, w, seed):
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([(yy * 3 + seed * 40) % 256, (xx * 2 + seed * 90) % 256, (yy + xx) % 256], -1).astype(np.uint8)
+    img = (img.astype(np.int32) + rng.integers(-20, 20, img.shape)).clip(0, 255).astype(np.uint8)
+    Image.fromarray(img).save(path)
+    return img
+
+
+def test_image_transfer_script(tmp_path):
+    """image_transfer.py call sequence end to end (files in, PNG out) against the oracle on the same pixels"""
+    from PIL import Image
+    import image_transfer
+    c = _png(tmp_path / "c.png", 50, 70, 1)                 # img_resize floors to 48 x 68
+    s = _png(tmp_path / "s.png", 40, 40, 2)
+    out = image_transfer.main(["--content", str(tmp_path / "c.png"), "--style", str(tmp_path / "s.png"),
+                               "--out_dir", str(tmp_path / "o"), "--synthetic_weights"])
+    got = np.asarray(Image.open(out))
+    from utils.utils import img_resize
+    ci = np.asarray(img_resize(Image.fromarray(c), 1280, 4)); si = np.asarray(img_resize(Image.fromarray(s), 1280, 4))
+    assert got.shape == ci.shape == (48, 68, 3)
+    sd = synthetic_state_dict(1234)
+    tt = lambda a: T(np.ascontiguousarray(a)).permute(2, 0, 1)[None].float().div(255)
+    with torch.no_grad():
+        ref = cpu_ref.to_uint8(cpu_ref.stylize(tt(ci), tt(si), sd, 2)[3])[0].numpy()
+    d = np.abs(got.astype(int) - ref.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-2
+
+
+def test_video_transfer_script_sharded(tmp_path):
+    """video_transfer.py on a directory of frames, two shards: every frame written once, equal to single-frame runs"""
+    from PIL import Image
+    import video_transfer
+    fd = tmp_path / "clip"
+    fd.mkdir()
+    for i in range(3):
+        _png(fd / f"{i:03d}.png", 32, 48, 10 + i)
+    _png(tmp_path / "s.png", 36, 36, 3)
+    outs = [video_transfer.main(["--video", str(fd), "--style", str(tmp_path / "s.png"), "--out_dir", str(tmp_path / "o"),
+                                 "--synthetic_weights", "--shard", f"{r}/2"]) for r in range(2)]
+    if os.path.isdir(outs[0]) and not any(f.endswith(".mp4") for f in os.listdir(tmp_path / "o")):
+        names = sorted(os.listdir(outs[0]))
+        assert names == ["00000.png", "00001.png", "00002.png"]
+        import image_transfer
+        single = image_transfer.main(["--content", str(fd / "001.png"), "--style", str(tmp_path / "s.png"),
+                                      "--out_dir", str(tmp_path / "o1"), "--synthetic_weights"])
+        assert np.array_equal(np.asarray(Image.open(os.path.join(outs[0], "00001.png"))), np.asarray(Image.open(single)))

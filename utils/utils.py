@@ -1,0 +1,57 @@
+"""Host-side helpers of the reference's inference scripts (reference: utils/utils.py:90-153), without the
+torchvision dependency.  Only what image_transfer.py / video_transfer.py use."""
+import os
+
+import numpy as np
+from PIL import Image
+
+# label colours of hand-made segmentation maps, in the reference's dictionary order (utils/utils.py:106-116)
+SEG_COLORS = [((0, 0, 255), 3), ((0, 255, 0), 2), ((0, 0, 0), 0), ((255, 255, 255), 1), ((255, 0, 0), 4),
+              ((255, 255, 0), 5), ((128, 128, 128), 6), ((0, 255, 255), 7), ((255, 0, 255), 8)]
+
+
+def img_resize(img, max_size, down_scale=None):
+    """utils/utils.py:90-101 — bicubic shrink so the long edge is <= max_size, then floor both edges to a
+    multiple of down_scale (a second bicubic resize)."""
+    w, h = img.size
+    if max(w, h) > max_size:
+        w = int(1.0 * img.size[0] / max(img.size) * max_size)
+        h = int(1.0 * img.size[1] / max(img.size) * max_size)
+        img = img.resize((w, h), Image.BICUBIC)
+    if down_scale is not None:
+        w = w // down_scale * down_scale
+        h = h // down_scale * down_scale
+        img = img.resize((w, h), Image.BICUBIC)
+    return img
+
+
+def colors_to_labels(arr):
+    """RGB [H,W,3] uint8 -> label map uint8 [H,W] (utils/utils.py:105-136): exact colour match, otherwise the
+    colour with the smallest L1 distance; ties keep the earlier dictionary entry (the reference's tie branch
+    raises inside a try/except and leaves the first minimum in place).  Vectorised instead of an O(HW) Python loop."""
+    arr = np.asarray(arr)
+    keys = np.array([c for c, _ in SEG_COLORS], dtype=np.int64)            # [9,3]
+    vals = np.array([v for _, v in SEG_COLORS], dtype=np.uint8)
+    dist = np.abs(arr.astype(np.int64)[:, :, None, :] - keys[None, None, :, :]).sum(-1)   # [H,W,9]
+    return vals[np.argmin(dist, axis=-1)]                                   # argmin returns the first minimum
+
+
+def load_segment(image_path, size=None):
+    """utils/utils.py:104-153 — hand-made colour segmentation -> label map (optionally NEAREST-resized to size=(w,h))."""
+    if not os.path.exists(image_path):
+        print("Can not find image path: %s " % image_path)
+        return None
+    image = Image.open(image_path).convert("RGB")
+    if size is not None:
+        w, h = size
+        image = image.resize((w, h), Image.NEAREST)
+    image = np.array(image)
+    if len(image.shape) == 3:
+        image = colors_to_labels(image)
+    return image
+
+
+def to_tensor_u8(img):
+    """PIL RGB image -> uint8 torch tensor [1,H,W,3] (the device side applies ToTensor's /255, RevResNet.forward_u8)."""
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(img.convert("RGB"), dtype=np.uint8)))[None]

@@ -1,0 +1,133 @@
+#!/usr/bin/env python
+"""Video (frame-sequence) style transfer — drop-in for the reference's video_transfer.py (video_transfer.py:17-38,
+160-214) on the MI355X HIP path.
+
+Differences that do not change pixels: the style is encoded and factored ONCE (the reference re-encodes it for
+every frame, :195); frames move as uint8 and are quantised on the device.  The writer-size quirk of the
+reference is kept (:83-86: video_width is overwritten before it scales video_height, so a 1920x1080 clip at
+--max_size 1280 is written at 1280x1080 while frames are stylised at 1280x720).
+--video may be a directory of frames (always works) or a video file (needs cv2, optional).  Output: an .mp4 if
+cv2 is importable, else numbered PNGs.  --shard i/n processes the i-th contiguous shard of the frames (one
+process per GPU; frames are independent).
+"""
+import argparse
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from PIL import Image
+
+from image_transfer import build_network
+from utils.utils import img_resize, load_segment, to_tensor_u8
+from vstnet_amd.sharding import shard_range
+
+IMG_EXT = ('.jpg', '.jpeg', '.png', '.ppm', '.bmp')
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument('--mode', type=str, default='photorealistic')
+    p.add_argument('--ckpoint', type=str, default='checkpoints/photo_video.pt')
+    p.add_argument('--video', type=str, default='data/content/03.avi')
+    p.add_argument('--style', type=str, default='data/style/03.jpeg')
+    p.add_argument('--out_dir', type=str, default="output")
+    p.add_argument('--max_size', type=int, default=1280)
+    p.add_argument('--alpha_c', type=float, default=None)
+    p.add_argument('--fps', type=int, default=30)
+    p.add_argument('--content_seg', type=str, default=None, help="one label map used for every frame")
+    p.add_argument('--style_seg', type=str, default=None)
+    p.add_argument('--auto_seg', action='store_true', default=False)
+    p.add_argument('--synthetic_weights', action='store_true', default=False)
+    p.add_argument('--shard', type=str, default="0/1")
+    return p
+
+
+def read_frames(path):
+    if os.path.isdir(path):
+        files = sorted(os.path.join(path, f) for f in os.listdir(path) if f.lower().endswith(IMG_EXT))
+        return [Image.open(f).convert('RGB') for f in files]
+    try:
+        import cv2
+    except ImportError as e:
+        raise RuntimeError("reading a video file needs cv2; pass a directory of frames instead") from e
+    frames, cap = [], cv2.VideoCapture(path)
+    while True:
+        ret, frame = cap.read()
+        if ret is False:
+            break
+        frames.append(Image.fromarray(frame[..., ::-1]))
+    return frames
+
+
+def writer_size(first_frame, max_size):
+    """video_transfer.py:82-86, including its overwrite-before-use quirk."""
+    video_height, video_width = np.array(first_frame).shape[:2]
+    if max(video_width, video_height) > max_size:
+        video_width = int(1.0 * video_width / max(video_width, video_height) * max_size)
+        video_height = int(1.0 * video_height / max(video_width, video_height) * max_size)
+    return video_width, video_height
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.auto_seg:
+        raise NotImplementedError("--auto_seg needs mmseg/SegFormer (not part of this repository)")
+    device = torch.device("cuda")
+    os.makedirs(args.out_dir, exist_ok=True)
+    net = build_network(args.mode, args.ckpoint, args.synthetic_weights, device)
+    from models.cWCT import cWCT
+    cwct = cWCT()
+
+    frames = read_frames(args.video)
+    rank, world = (int(v) for v in args.shard.split("/"))
+    lo, hi = shard_range(len(frames), rank, world)
+    video_width, video_height = writer_size(frames[0], args.max_size)
+
+    style = img_resize(Image.open(args.style).convert('RGB'), args.max_size, down_scale=net.down_scale)
+    masked = args.content_seg is not None and args.style_seg is not None
+    with torch.no_grad():
+        z_s = net.forward_u8(to_tensor_u8(style).to(device))
+        s_stats = cwct.style_stats(z_s) if not masked and args.alpha_c is None else None
+    style_seg = load_segment(args.style_seg, style.size)[None, ...] if masked else None
+
+    name = "%s_%s" % (os.path.basename(args.video.rstrip("/")).split(".")[0], os.path.basename(args.style).split(".")[0])
+    writer, frame_dir = None, None
+    try:
+        import cv2
+        writer = cv2.VideoWriter(os.path.join(args.out_dir, name + (".mp4" if world == 1 else "_%d.mp4" % rank)),
+                                 cv2.VideoWriter_fourcc('m', 'p', '4', 'v'), args.fps, (video_width, video_height))
+    except ImportError:
+        frame_dir = os.path.join(args.out_dir, name)
+        os.makedirs(frame_dir, exist_ok=True)
+
+    for i in range(lo, hi):
+        content = img_resize(frames[i], args.max_size, down_scale=net.down_scale)
+        content_seg = load_segment(args.content_seg, content.size)[None, ...] if masked else None
+        with torch.no_grad():
+            z_c = net.forward_u8(to_tensor_u8(content).to(device))
+            if args.alpha_c is not None and not masked:
+                assert 0.0 <= args.alpha_c <= 1.0
+                z_cs = cwct.interpolation(z_c, styl_feat_list=[z_s], alpha_s_list=[1.0], alpha_c=args.alpha_c)
+            elif masked:
+                z_cs = cwct.transfer(z_c, z_s, content_seg, style_seg)
+            else:
+                z_cs = cwct.transfer_with_stats(z_c, s_stats)
+            if (content.size[0], content.size[1]) == (video_width, video_height):
+                out = net.inverse_u8(z_cs)[0].cpu().numpy()
+            else:       # transforms.Resize((video_height, video_width), BICUBIC) on the float tensor, then quantise
+                sty = net(z_cs, forward=False)
+                sty = F.interpolate(sty, size=(video_height, video_width), mode="bicubic", align_corners=False, antialias=True)
+                out = sty[0].mul(255).clamp(0, 255).byte().permute(1, 2, 0).cpu().numpy()
+        if writer is not None:
+            writer.write(out[..., ::-1])
+        else:
+            Image.fromarray(out).save(os.path.join(frame_dir, "%05d.png" % i))
+    if writer is not None:
+        writer.release()
+    print("Save stylized video at %s" % (frame_dir or args.out_dir))
+    return frame_dir or args.out_dir
+
+
+if __name__ == "__main__":
+    main()

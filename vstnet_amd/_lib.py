@@ -23,7 +23,8 @@ PREC_FP32 = 1
 # every symbol include/vstnet.h declares
 EXPORTS = [
     "vst_version", "vst_error_string", "vst_conv_packed_bytes", "vst_pack_conv", "vst_pack_input",
-    "vst_unpack_output", "vst_spread", "vst_gather", "vst_block_tmp_bytes", "vst_block_apply",
+    "vst_unpack_output", "vst_pack_input_u8", "vst_unpack_output_u8", "vst_revnet_forward_u8", "vst_revnet_inverse_u8",
+    "vst_spread", "vst_gather", "vst_block_tmp_bytes", "vst_block_apply",
     "vst_pass_workspace_bytes", "vst_revnet_forward", "vst_revnet_inverse",
     "vst_cwct_stats_workspace_bytes", "vst_cwct_stats", "vst_cwct_factor", "vst_cwct_apply",
     "vst_cwct_prefactor", "vst_profile_begin", "vst_profile_end",
@@ -80,6 +81,10 @@ def lib() -> C.CDLL:
         "vst_pack_conv": (i, [vp, i, i, vp, vp]),
         "vst_pack_input": (i, [vp, vp, vp, i, i, i, i, vp]),
         "vst_unpack_output": (i, [vp, vp, i, i, i, i, vp]),
+        "vst_pack_input_u8": (i, [vp, vp, vp, i, i, i, vp]),
+        "vst_unpack_output_u8": (i, [vp, vp, i, i, i, vp]),
+        "vst_revnet_forward_u8": (i, [C.POINTER(NetWeights), vp, vp, vp, i, i, i, i, i, vp]),
+        "vst_revnet_inverse_u8": (i, [C.POINTER(NetWeights), vp, vp, vp, i, i, i, i, i, vp]),
         "vst_spread": (i, [vp, vp, vp, i, i, i, i, vp]),
         "vst_gather": (i, [vp, vp, vp, i, i, i, i, vp]),
         "vst_block_tmp_bytes": (sz, [i, i, i]),

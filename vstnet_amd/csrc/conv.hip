@@ -657,13 +657,13 @@ static int pass_sub_batch(int B, int H, int W) {
     return nb > (size_t)B ? B : (int)nb;
 }
 
-static int revnet_forward_chunk(const vst_net_weights* w, const float* x, float* z, void* workspace, int B, int C_in,
-                                int H, int W, int sp_steps, int precision, void* stream) {
+static int revnet_forward_chunk(const vst_net_weights* w, const float* x, const uint8_t* x_u8, float* z, void* workspace,
+                                int B, int C_in, int H, int W, int sp_steps, int precision, void* stream) {
     float* s[2];
     s[0] = (float*)workspace;
     s[1] = s[0] + (size_t)B * H * W * 16;
     float* tmp = s[1] + (size_t)B * H * W * 16;
-    int rc = vst_pack_input(x, s[0], s[1], B, C_in, H, W, stream);
+    int rc = x_u8 ? vst_pack_input_u8(x_u8, s[0], s[1], B, H, W, stream) : vst_pack_input(x, s[0], s[1], B, C_in, H, W, stream);
     if (rc) return rc;
     for (int k = 0; k < VST_NUM_BLOCKS; ++k) {
         rc = vst_block_apply(&w->blocks[k], kBlockChannel[k], kBlockStride[k], +1, precision, s[k & 1], s[1 - (k & 1)],
@@ -673,8 +673,8 @@ static int revnet_forward_chunk(const vst_net_weights* w, const float* x, float*
     return vst_spread(s[0], s[1], z, B, H, W, sp_steps, stream);
 }
 
-static int revnet_inverse_chunk(const vst_net_weights* w, const float* z, float* x, void* workspace, int B, int C_out,
-                                int H, int W, int sp_steps, int precision, void* stream) {
+static int revnet_inverse_chunk(const vst_net_weights* w, const float* z, float* x, uint8_t* x_u8, void* workspace, int B,
+                                int C_out, int H, int W, int sp_steps, int precision, void* stream) {
     float* s[2];
     s[0] = (float*)workspace;
     s[1] = s[0] + (size_t)B * H * W * 16;
@@ -686,12 +686,12 @@ static int revnet_inverse_chunk(const vst_net_weights* w, const float* z, float*
                              tmp, B, H, W, stream);
         if (rc) return rc;
     }
-    return vst_unpack_output(s[0], x, B, C_out, H, W, stream);
+    return x_u8 ? vst_unpack_output_u8(s[0], x_u8, B, H, W, stream) : vst_unpack_output(s[0], x, B, C_out, H, W, stream);
 }
 
-int vst_revnet_forward(const vst_net_weights* w, const float* x, float* z, void* workspace, int B, int C_in, int H,
-                       int W, int sp_steps, int precision, void* stream) {
-    if (!w || !x || !z) return VST_E_ARG;
+static int revnet_forward_any(const vst_net_weights* w, const float* x, const uint8_t* x_u8, float* z, void* workspace,
+                              int B, int C_in, int H, int W, int sp_steps, int precision, void* stream) {
+    if (!w || (!x && !x_u8) || !z) return VST_E_ARG;
     if (!workspace) return VST_E_WORKSPACE;
     if (!vst_shape_ok(B, H, W) || C_in < 1 || C_in > 16) return VST_E_SHAPE;
     if (sp_steps != 1 && sp_steps != 2) return VST_E_MODE;
@@ -699,16 +699,17 @@ int vst_revnet_forward(const vst_net_weights* w, const float* x, float* z, void*
     const size_t zimg = (size_t)32 * H * W;                 // floats per image of z in both modes
     for (int b0 = 0; b0 < B; b0 += nb) {
         const int n = B - b0 < nb ? B - b0 : nb;
-        const int rc = revnet_forward_chunk(w, x + (size_t)b0 * C_in * H * W, z + (size_t)b0 * zimg, workspace, n, C_in, H,
-                                            W, sp_steps, precision, stream);
+        const int rc = revnet_forward_chunk(w, x ? x + (size_t)b0 * C_in * H * W : nullptr,
+                                            x_u8 ? x_u8 + (size_t)b0 * H * W * 3 : nullptr, z + (size_t)b0 * zimg,
+                                            workspace, n, C_in, H, W, sp_steps, precision, stream);
         if (rc) return rc;
     }
     return VST_OK;
 }
 
-int vst_revnet_inverse(const vst_net_weights* w, const float* z, float* x, void* workspace, int B, int C_out, int H,
-                       int W, int sp_steps, int precision, void* stream) {
-    if (!w || !x || !z) return VST_E_ARG;
+static int revnet_inverse_any(const vst_net_weights* w, const float* z, float* x, uint8_t* x_u8, void* workspace, int B,
+                              int C_out, int H, int W, int sp_steps, int precision, void* stream) {
+    if (!w || (!x && !x_u8) || !z) return VST_E_ARG;
     if (!workspace) return VST_E_WORKSPACE;
     if (!vst_shape_ok(B, H, W) || C_out < 1 || C_out > 16) return VST_E_SHAPE;
     if (sp_steps != 1 && sp_steps != 2) return VST_E_MODE;
@@ -716,11 +717,36 @@ int vst_revnet_inverse(const vst_net_weights* w, const float* z, float* x, void*
     const size_t zimg = (size_t)32 * H * W;
     for (int b0 = 0; b0 < B; b0 += nb) {
         const int n = B - b0 < nb ? B - b0 : nb;
-        const int rc = revnet_inverse_chunk(w, z + (size_t)b0 * zimg, x + (size_t)b0 * C_out * H * W, workspace, n, C_out,
-                                            H, W, sp_steps, precision, stream);
+        const int rc = revnet_inverse_chunk(w, z + (size_t)b0 * zimg, x ? x + (size_t)b0 * C_out * H * W : nullptr,
+                                            x_u8 ? x_u8 + (size_t)b0 * H * W * 3 : nullptr, workspace, n, C_out, H, W,
+                                            sp_steps, precision, stream);
         if (rc) return rc;
     }
     return VST_OK;
+}
+
+int vst_revnet_forward(const vst_net_weights* w, const float* x, float* z, void* workspace, int B, int C_in, int H,
+                       int W, int sp_steps, int precision, void* stream) {
+    if (!x) return VST_E_ARG;
+    return revnet_forward_any(w, x, nullptr, z, workspace, B, C_in, H, W, sp_steps, precision, stream);
+}
+
+int vst_revnet_inverse(const vst_net_weights* w, const float* z, float* x, void* workspace, int B, int C_out, int H,
+                       int W, int sp_steps, int precision, void* stream) {
+    if (!x) return VST_E_ARG;
+    return revnet_inverse_any(w, z, x, nullptr, workspace, B, C_out, H, W, sp_steps, precision, stream);
+}
+
+int vst_revnet_forward_u8(const vst_net_weights* w, const uint8_t* frames_hwc, float* z, void* workspace, int B, int H,
+                          int W, int sp_steps, int precision, void* stream) {
+    if (!frames_hwc) return VST_E_ARG;
+    return revnet_forward_any(w, nullptr, frames_hwc, z, workspace, B, 3, H, W, sp_steps, precision, stream);
+}
+
+int vst_revnet_inverse_u8(const vst_net_weights* w, const float* z, uint8_t* frames_hwc, void* workspace, int B, int H,
+                          int W, int sp_steps, int precision, void* stream) {
+    if (!frames_hwc) return VST_E_ARG;
+    return revnet_inverse_any(w, z, nullptr, frames_hwc, workspace, B, 3, H, W, sp_steps, precision, stream);
 }
 
 }  // extern "C"

@@ -39,6 +39,41 @@ __global__ __launch_bounds__(256) void unpack_output_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// uint8 HWC frame edge.  In: transforms.ToTensor (image_transfer.py:167, video_transfer.py:188):
+// x = u8 / 255 as fp32, HWC -> channel planes.  Out: grid.mul(255).clamp(0, 255).byte() with truncation + CHW -> HWC
+// (image_transfer.py:217-218, video_transfer.py:212).  Frames cross PCIe as 3 bytes per pixel instead of 12.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_input_u8_kernel(const uint8_t* __restrict__ img, float* __restrict__ s1,
+                                                            int H, int W) {
+    const int xg = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int yg = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (xg >= W || yg >= H) return;
+    const uint8_t* src = img + ((size_t)b * H * W + (size_t)yg * W + xg) * 3;
+    float* dst = s1 + (size_t)b * H * W * 16 + zc_offset(0, yg, xg, W >> 2);
+    *(float4*)(dst) = make_float4((float)src[0] / 255.f, (float)src[1] / 255.f, (float)src[2] / 255.f, 0.f);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    *(float4*)(dst + 4) = z; *(float4*)(dst + 8) = z; *(float4*)(dst + 12) = z;
+}
+
+__global__ __launch_bounds__(256) void unpack_output_u8_kernel(const float* __restrict__ s1, uint8_t* __restrict__ img,
+                                                               int H, int W) {
+    const int xg = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int yg = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (xg >= W || yg >= H) return;
+    const float4 v = *(const float4*)(s1 + (size_t)b * H * W * 16 + zc_offset(0, yg, xg, W >> 2));
+    uint8_t* dst = img + ((size_t)b * H * W + (size_t)yg * W + xg) * 3;
+    const float c[3] = {v.x, v.y, v.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float t = c[k] * 255.f;
+        t = t < 0.f ? 0.f : (t > 255.f ? 255.f : t);       // NaN falls through both compares like torch.clamp keeps NaN; byte() of it is 0
+        dst[k] = (uint8_t)t;                               // truncation toward zero
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // spread / gather.  m = cat(s1, s2) has 512 channels per quarter-res cell.
 //   SP == 2:  z[d32 , 4h+2i+i', 4w+2j+j'] = m[(2i+j)*128 + (2i'+j')*32 + d32 ][h][w]
 //   SP == 1:  z[d128, 2h+i    , 2w+j    ] = m[(2i+j)*128 + d128             ][h][w]
@@ -204,6 +239,25 @@ int vst_unpack_output(const float* s1, float* x, int B, int C, int H, int W, voi
     if (!x || !s1) return VST_E_ARG;
     if (!vst_shape_ok(B, H, W) || C < 1 || C > 16) return VST_E_SHAPE;
     unpack_output_kernel<<<dim3((W + 63) / 64, (H + 3) / 4, B), 256, 0, (hipStream_t)stream>>>(s1, x, C, H, W);
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
+int vst_pack_input_u8(const uint8_t* frames_hwc, float* s1, float* s2, int B, int H, int W, void* stream) {
+    if (!frames_hwc || !s1 || !s2) return VST_E_ARG;
+    if (!vst_shape_ok(B, H, W)) return VST_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(s2, 0, (size_t)B * H * W * 16 * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    pack_input_u8_kernel<<<dim3((W + 63) / 64, (H + 3) / 4, B), 256, 0, st>>>(frames_hwc, s1, H, W);
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
+int vst_unpack_output_u8(const float* s1, uint8_t* frames_hwc, int B, int H, int W, void* stream) {
+    if (!frames_hwc || !s1) return VST_E_ARG;
+    if (!vst_shape_ok(B, H, W)) return VST_E_SHAPE;
+    unpack_output_u8_kernel<<<dim3((W + 63) / 64, (H + 3) / 4, B), 256, 0, (hipStream_t)stream>>>(s1, frames_hwc, H, W);
     VST_RETURN_IF_LAUNCH_FAILED();
     return VST_OK;
 }

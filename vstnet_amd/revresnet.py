@@ -187,6 +187,46 @@ class RevResNet(nn.Module):
                                             _PRECISIONS[self.precision], _stream_ptr()), "vst_revnet_inverse")
         return x
 
+    # ------------------------------------------------------------------ uint8 frame edge
+    def forward_u8(self, frames):
+        """Encode uint8 HWC frames [B,H,W,3] (what PIL / cv2 hand over) — ToTensor's u8/255 scaling and the
+        HWC->planes transpose happen inside the first boundary kernel (image_transfer.py:167, video_transfer.py:188)."""
+        if not frames.is_cuda or frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3:
+            raise RuntimeError("forward_u8 expects a CUDA uint8 tensor [B,H,W,3]")
+        if self.in_channel != 3:
+            raise RuntimeError("forward_u8 needs in_channel == 3")
+        frames = frames.contiguous()
+        B, H, W, _ = frames.shape
+        if H % 4 or W % 4 or H < 8 or W < 8:
+            raise RuntimeError(f"H and W must be multiples of 4 and >= 8 (got {H}x{W})")
+        L = _lib.lib()
+        net = self._ensure_packed(frames.device)
+        s = self.sp_steps
+        z = torch.empty((B, 32, H, W) if s == 2 else (B, 128, H // 2, W // 2), dtype=torch.float32, device=frames.device)
+        ws = self._get_workspace(L.vst_pass_workspace_bytes(B, H, W), frames.device)
+        with torch.cuda.device(frames.device):
+            _lib.check(L.vst_revnet_forward_u8(C.byref(net), C.c_void_p(frames.data_ptr()), C.c_void_p(z.data_ptr()),
+                                               C.c_void_p(ws.data_ptr()), B, H, W, s, _PRECISIONS[self.precision],
+                                               _stream_ptr()), "vst_revnet_forward_u8")
+        return z
+
+    def inverse_u8(self, z):
+        """Decode a code to uint8 HWC frames with the reference's quantisation: mul(255).clamp(0,255).byte()
+        (truncation; image_transfer.py:217-218, video_transfer.py:212) fused into the last boundary kernel."""
+        s = self.sp_steps
+        z = self._check(z, 32 if s == 2 else 128, "RevResNet inverse input")
+        B = z.shape[0]
+        H, W = (z.shape[2], z.shape[3]) if s == 2 else (z.shape[2] * 2, z.shape[3] * 2)
+        L = _lib.lib()
+        net = self._ensure_packed(z.device)
+        out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=z.device)
+        ws = self._get_workspace(L.vst_pass_workspace_bytes(B, H, W), z.device)
+        with torch.cuda.device(z.device):
+            _lib.check(L.vst_revnet_inverse_u8(C.byref(net), C.c_void_p(z.data_ptr()), C.c_void_p(out.data_ptr()),
+                                               C.c_void_p(ws.data_ptr()), B, H, W, s, _PRECISIONS[self.precision],
+                                               _stream_ptr()), "vst_revnet_inverse_u8")
+        return out
+
     @torch.no_grad()
     def sample(self, transfer_module, x_c, x_s, device):
         """models/RevResNet.py:241-263 (training-log helper; the fork's pdb trap is dropped)."""
