@@ -305,3 +305,45 @@ def colors_to_labels_loop(arr):
                     best_d, best = d, val
             out[x, y] = best
     return out.astype(np.uint8)
+
+
+class SegReMappingLoop:
+    """models/segmentation/SegReMapping.py:5-76 restated with the reference's per-label `seg == label` scans."""
+
+    def __init__(self, label_mapping, min_ratio=0.01):
+        self.label_mapping = np.asarray(label_mapping)
+        self.min_ratio = min_ratio
+
+    def cross_remapping(self, content_seg, style_seg):
+        cont = list(np.unique(content_seg))
+        style = list(np.unique(style_seg))
+        new = list(cont)
+        for s in set(cont) - set(style):
+            for j in range(self.label_mapping.shape[0]):
+                cand = self.label_mapping[j, s]
+                if cand in style:
+                    new[cont.index(s)] = cand
+                    break
+        out = content_seg.copy()
+        for i, cur in enumerate(cont):
+            out[content_seg == cur] = new[i]
+        return out
+
+    def self_remapping(self, seg):
+        out = seg.copy()
+        n = seg.shape[0] * seg.shape[1]
+        labels, ratios = [], []
+        for l in np.unique(seg):
+            labels.append(l)
+            ratios.append(np.sum(np.float32(seg == l)) / n)
+        new = list(labels)
+        for i, cur in enumerate(labels):
+            if ratios[i] < self.min_ratio:
+                for j in range(self.label_mapping.shape[0]):
+                    cand = self.label_mapping[j, cur]
+                    if cand in labels and ratios[labels.index(cand)] >= self.min_ratio:
+                        new[i] = cand
+                        break
+        for i, cur in enumerate(labels):
+            out[seg == cur] = new[i]
+        return out

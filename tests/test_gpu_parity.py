@@ -398,3 +398,22 @@ def test_video_transfer_script_sharded(tmp_path):
         single = image_transfer.main(["--content", str(fd / "001.png"), "--style", str(tmp_path / "s.png"),
                                       "--out_dir", str(tmp_path / "o1"), "--synthetic_weights"])
         assert np.array_equal(np.asarray(Image.open(os.path.join(outs[0], "00001.png"))), np.asarray(Image.open(single)))
+
+
+def test_masked_art_mode_with_resized_masks():
+    """8(f) rank 3: label maps at image resolution, artistic codes at half resolution -> NEAREST resize (upstream rule)"""
+    from models.cWCT import cWCT
+    net, sd, sp = make_net("art")
+    cw = cWCT(resize_masks=True)
+    H, W = 96, 160
+    xc, xs = synthetic_frames(1, H, W, seed=31), synthetic_frames(1, 80, 112, seed=32)
+    cm, sm = synthetic_mask(H, W, 3, seed=5)[None], synthetic_mask(80, 112, 3, seed=6, speck=False)[None]
+    with torch.no_grad():
+        zc, zs = cpu_ref.revnet_forward(xc, sd, sp), cpu_ref.revnet_forward(xs, sd, sp)
+        cmr = cw.resize(cm[0], H // 2, W // 2)[None]
+        smr = cw.resize(sm[0], 40, 56)[None]
+        ref = cpu_ref.transfer_seg(zc, zs, cmr, smr)
+    got = cw.transfer(net(xc.cuda()), net(xs.cuda()), cm, sm)
+    assert_close(got, ref, 2e-3, "masked art z_cs", tol_max=2e-2)       # 128 channels, ~200-pixel regions: ill-conditioned
+    with pytest.raises(ValueError):
+        cWCT().transfer(net(xc.cuda()), net(xs.cuda()), cm, sm)

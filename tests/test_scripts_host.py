@@ -41,3 +41,20 @@ def test_writer_size_quirk():
     frame = Image.fromarray(np.zeros((1080, 1920, 3), np.uint8))
     assert writer_size(frame, 1280) == (1280, 1080)      # video_transfer.py:83-86: width is overwritten first
     assert writer_size(frame, 1920) == (1920, 1080)
+
+
+def test_seg_remapping_matches_reference_loops():
+    from models.segmentation.SegReMapping import SegReMapping
+    rng = np.random.default_rng(7)
+    K = 20
+    mapping = np.stack([rng.permutation(K) for _ in range(K)], axis=1)      # column l: related labels, best first
+    mapping[-1] = np.arange(K)                                               # the reference's table ends with identity
+    fast, slow = SegReMapping(mapping, min_ratio=0.02), cpu_ref.SegReMappingLoop(mapping, min_ratio=0.02)
+    for trial in range(5):
+        seg = rng.choice(K, size=(40, 56), p=rng.dirichlet(np.full(K, 0.3))).astype(np.uint8)
+        seg[0, :3] = (trial + 3) % K                                         # a tiny region -> remapped
+        sty = rng.choice(K, size=(30, 30), p=rng.dirichlet(np.full(K, 0.2))).astype(np.uint8)
+        a, b = fast.self_remapping(seg), slow.self_remapping(seg)
+        assert a.dtype == seg.dtype and np.array_equal(a, b)
+        assert np.array_equal(fast.cross_remapping(a, sty), slow.cross_remapping(b, sty))
+        assert np.array_equal(seg, seg.copy())

@@ -34,10 +34,13 @@ def _ptr(t):
 class cWCT(nn.Module):
     """Cholesky decomposition based WCT (HIP implementation)."""
 
-    def __init__(self, eps=2e-5, use_double=False):
+    def __init__(self, eps=2e-5, use_double=False, resize_masks=False):
         super().__init__()
         self.eps = eps
         self.use_double = use_double
+        # upstream CAP-VSTNet resized the label maps to the feature resolution (NEAREST, cWCT.py:191-197); this
+        # fork uses them as they are (:72-73), which only fits photorealistic codes.  Opt in to restore it.
+        self.resize_masks = resize_masks
         self._ws = None
         self.last_info = None      # device int32 [2+n_styles]: content retries, overflow flag, style retries
 
@@ -166,6 +169,11 @@ class cWCT(nn.Module):
         out = c.clone()
         for b in range(B):
             cm_np, sm_np = np.asarray(cmask[b]), np.asarray(smask[b])
+            if self.resize_masks:
+                if cm_np.shape != (cH, cW):
+                    cm_np = self.resize(np.ascontiguousarray(cm_np.astype(np.uint8)), cH, cW)
+                if sm_np.shape != (sH, sW):
+                    sm_np = self.resize(np.ascontiguousarray(sm_np.astype(np.uint8)), sH, sW)
             if cm_np.size != cH * cW or sm_np.size != sH * sW:
                 raise ValueError("masks must have the feature resolution "
                                  f"(content {cm_np.shape} vs {(cH, cW)}, style {sm_np.shape} vs {(sH, sW)})")
