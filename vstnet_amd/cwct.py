@@ -46,9 +46,14 @@ class cWCT(nn.Module):
 
     # ------------------------------------------------------------------ low-level wrappers
     def _workspace(self, nbytes, device):
-        if self._ws is None or self._ws.device != device or self._ws.numel() < nbytes:
-            self._ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        return self._ws
+        """Statistics workspace, one per (device, stream)."""
+        if self._ws is None:
+            self._ws = {}
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            self._ws[key] = ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        return ws
 
     @staticmethod
     def _prep(x):

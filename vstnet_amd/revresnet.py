@@ -135,9 +135,13 @@ class RevResNet(nn.Module):
         return net
 
     def _get_workspace(self, nbytes, device):
-        ws = self._workspace
-        if ws is None or ws.device != device or ws.numel() < nbytes:
-            self._workspace = ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        """Pass workspace, one per (device, stream): frames in flight on different streams must not share state."""
+        if self._workspace is None:
+            self._workspace = {}
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        ws = self._workspace.get(key)
+        if ws is None or ws.numel() < nbytes:
+            self._workspace[key] = ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         return ws
 
     # ------------------------------------------------------------------ the reference's call surface
