@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=None, help="frame height if not square (e.g. 1080 with --width 1920)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--masked", type=int, default=0, help="K > 0: per-region cWCT with K-label synthetic masks (config 5)")
     ap.add_argument("--mode", default="photo", choices=["photo", "art"])
     ap.add_argument("--frames-per-gpu", type=int, default=1)
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32"])
@@ -59,6 +62,8 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     S, fpg = args.size, args.frames_per_gpu
+    Hf, Wf = (args.height or S), (args.width or S)
+    Hf, Wf = Hf // 4 * 4, Wf // 4 * 4                     # img_resize floors to a multiple of down_scale = 4
     hd, sp = (16, 2) if args.mode == "photo" else (64, 1)
     sd = synthetic_state_dict(1234, hd, sp)
     net = RevResNet(hidden_dim=hd, sp_steps=sp, precision=args.precision)
@@ -72,9 +77,15 @@ def main():
     frames = []
     for f in range(first, last):
         rng = np.random.Generator(np.random.PCG64([0, f]))
-        frames.append(rng.random((3, S, S), dtype=np.float32))
+        frames.append(rng.random((3, Hf, Wf), dtype=np.float32))
     content = torch.from_numpy(np.stack(frames)).to(dev)
-    style = synthetic_frames(1, S, S, seed=1).to(dev)
+    style = synthetic_frames(1, Hf, Wf, seed=1).to(dev)
+    cmask = smask = None
+    if args.masked:
+        from vstnet_amd.synth import synthetic_mask
+        assert args.mode == "photo", "this fork's masked cWCT needs masks at code resolution (photorealistic codes)"
+        cmask = np.stack([synthetic_mask(Hf, Wf, args.masked, seed=3)] * fpg)
+        smask = np.stack([synthetic_mask(Hf, Wf, args.masked, seed=4, speck=False)] * fpg)
 
     with torch.no_grad():
         z_s = net(style)
@@ -82,7 +93,9 @@ def main():
 
         def stylize_batch():
             z_c = net(content, forward=True)
-            if args.recompute_style:
+            if args.masked:
+                z_cs = cw.transfer(z_c, z_s.expand(fpg, -1, -1, -1), cmask, smask)
+            elif args.recompute_style:
                 zs = net(style, forward=True)
                 z_cs = cw.transfer(z_c, zs.expand(fpg, -1, -1, -1))
             else:
@@ -113,7 +126,7 @@ def main():
         tot_ms, n_launch = C.c_double(0), C.c_int(0)
         _lib.check(L.vst_profile_end(C.byref(tot_ms), C.byref(n_launch)), "vst_profile_end")
         avg_ms = tot_ms.value / max(1, n_launch.value)
-        px = fpg * (S // 4) * (S // 4)
+        px = fpg * (Hf // 4) * (Wf // 4)
         alg_flops = 2.0 * 9 * cin * cout * px        # fp32-equivalent conv flops (the split executes 3x as bf16 MFMA)
         achieved_tf = alg_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
 
@@ -121,7 +134,7 @@ def main():
     # command; FETCH_SIZE corrected x2 for gfx950) — only valid for the workload it was taken on
     traffic = None
     pmc_path = os.path.join(REPO, "profiles", "r01_pmc_hbm_traffic.json")
-    if os.path.exists(pmc_path) and S == 1024 and fpg == 1 and args.mode == "photo":
+    if os.path.exists(pmc_path) and (Hf, Wf) == (1024, 1024) and fpg == 1 and args.mode == "photo":
         k = json.load(open(pmc_path))["kernels"].get(f"void conv_pipe_kernel<{cin}, {cout}, true, false>(ConvArgs)")
         traffic = k["hbm_bytes_per_launch"] if k else None
 
@@ -129,7 +142,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = frames_total / elapsed
     passes = 3 if args.recompute_style else 2
-    frame_bytes = (passes * 6540 + 384) * S * S + (128 * S * S if args.recompute_style else 0)
+    frame_bytes = (passes * 6540 + 384) * Hf * Wf + (128 * Hf * Wf if args.recompute_style else 0)
     frame_gbs = frame_bytes * fpg * args.steps / elapsed / 1e9     # per GPU
 
     rec = {
@@ -138,8 +151,8 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (bf16x3 split MFMA, f32 accumulate/state)" if args.precision == "bf16x3" else "f32",
         "data": "synthetic",
-        "config": {"workload": f"{'photorealistic' if args.mode == 'photo' else 'artistic'} {S}x{S} frame: RevResNet "
-                   f"forward + cWCT ({'style re-encoded per frame' if args.recompute_style else 'style statistics cached'})"
+        "config": {"workload": f"{'photorealistic' if args.mode == 'photo' else 'artistic'} {Wf}x{Hf} frame: RevResNet "
+                   f"forward + cWCT ({str(args.masked) + '-label masked, ' if args.masked else ''}{'style re-encoded per frame' if args.recompute_style else 'style statistics cached'})"
                    " + RevResNet inverse", "frames_per_gpu": fpg, "sharding": f"{world} ranks x {fpg} frame(s), no collective",
                    "weights": "synthetic seed 1234", "frames_in_flight": max(1, args.streams)},
         "roofline": {"kernel": f"conv_pipe_kernel<{cin},{cout}> (stage-3 / channel_reduction conv.1)", "bound": "mfma",
@@ -153,7 +166,7 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        rec["cpu_baseline"] = cpu_baseline(sd, sp, S)
+        rec["cpu_baseline"] = cpu_baseline(sd, sp, Hf, Wf)
     if rank == 0:
         print(json.dumps(rec), flush=True)
     if world > 1:
@@ -173,7 +186,7 @@ def usable_cores():
     return max(1, min(n, int(os.environ.get("VST_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(sd, sp, S):
+def cpu_baseline(sd, sp, H, W):
     """The oracle (CPU restatement of the reference's torch-op sequence) timed on this host's cores on ONE
     frame of the same workload (style code precomputed, like the GPU leg)."""
     import torch
@@ -181,7 +194,7 @@ def cpu_baseline(sd, sp, S):
     from vstnet_amd.synth import synthetic_frames
     cores = usable_cores()
     torch.set_num_threads(cores)
-    xc, xs = synthetic_frames(1, S, S, seed=0), synthetic_frames(1, S, S, seed=1)
+    xc, xs = synthetic_frames(1, H, W, seed=0), synthetic_frames(1, H, W, seed=1)
     with torch.no_grad():
         small = synthetic_frames(1, 64, 64, seed=2)
         cpu_ref.revnet_inverse(cpu_ref.revnet_forward(small, sd, sp), sd, sp)       # warm the thread pool
@@ -192,7 +205,7 @@ def cpu_baseline(sd, sp, S):
         cpu_ref.revnet_inverse(zcs, sd, sp)
         dt = time.perf_counter() - t0
     return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 frame {S}x{S} (forward + cWCT + inverse, style code precomputed), oracle/cpu_ref.py on torch CPU ops",
+            "sample": f"1 frame {W}x{H} (forward + cWCT + inverse, style code precomputed), oracle/cpu_ref.py on torch CPU ops",
             "seconds": round(dt, 2)}
 
 

@@ -16,6 +16,10 @@
 // fragment order (layout.hip) and copied straight into LDS.
 #include "common.h"
 
+#ifndef VST_ABLATE
+#define VST_ABLATE 0
+#endif
+
 struct ConvArgs {
     const float* in;
     float* out;
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const ConvArgs a) {
             const int s = q * 3 + dy;
             const int cur = (qq * 3 + dy) & 1;            // compile-time parity of s
             // ---- issue the loads that are two stages ahead (consumed from registers during the NEXT stage) ----
-            {   // weights of stage s+2
+            if (!(VST_ABLATE & 2)) {   // weights of stage s+2
                 const int q2 = dy == 0 ? q : q + 1, dy2 = (dy + 2) % 3;
                 if (q2 < Q) rb[cur] = load_b(q2, dy2);
                 // activations stored during stage s+1 = (qn, dyn): part dyn of chunk(qn)+1 (first output slice only)
@@ -441,8 +445,10 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const ConvArgs a) {
             }
 
             // ---- land what was loaded one stage ago in the buffers of stage s+1 (free since the last barrier) -------
+            if (!(VST_ABLATE & 2)) {
             if (s + 1 < 3 * Q) store_b((s + 1) & 1, rb[cur ^ 1]);
             if (q < C::NCHUNK - 1) STORE_A((chunk + 1) & 1, dy, ra[cur ^ 1]);
+            }
 
             // ---- 3 k-steps of MFMAs on the current buffers; fragments are double-buffered in registers: the reads
             //      of k-step k+1 are issued before the MFMAs of k-step k --------------------------------------------
@@ -453,9 +459,9 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const ConvArgs a) {
 #pragma unroll
             for (int k3 = 0; k3 < 3; ++k3) {
                 __builtin_amdgcn_sched_barrier(0);            // reads of k-step k3+1 stay ahead of the MFMAs of k3
-                if (k3 < 2) read_frags(fr[(k3 + 1) & 1], Ab, Bb, k3 + 1);
+                if (k3 < 2 && !(VST_ABLATE & 1)) read_frags(fr[(k3 + 1) & 1], Ab, Bb, k3 + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                const Frags& f = fr[k3 & 1];
+                const Frags& f = fr[(VST_ABLATE & 1) ? 0 : (k3 & 1)];
 #pragma unroll
                 for (int m = 0; m < C::MR; ++m)
 #pragma unroll
