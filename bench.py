@@ -52,11 +52,16 @@ def main():
 
     from vstnet_amd.sharding import dist_env, shard_range, timed_steps
     rank, local_rank, world = dist_env()
+    n_dev = torch.cuda.device_count()
+    use_nccl = world <= n_dev                 # fewer GPUs than ranks (rehearsal on a 1-GPU box): ranks share GPUs, gloo
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(local_rank % n_dev)
+        if use_nccl:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -114,7 +119,7 @@ def main():
             with torch.cuda.stream(st):
                 return stylize_batch()
 
-        elapsed = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, world, device=dev)
+        elapsed = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, world, device=dev if use_nccl else "cpu")
         assert torch.isfinite(step()).all()
 
         # ---- live roofline of the dominant kernel: HIP events around each of its launches ------------
