@@ -65,3 +65,8 @@ __host__ __device__ inline PackedConvLayout packed_conv_layout(int cout, int cin
     p.frag_bytes = (size_t)p.ksteps * 4 * p.coutp * 16;
     return p;
 }
+
+// internal (not part of the C ABI): input packing with the constant of forward block 0 folded in
+extern "C" int vst_pack_input_k(const float* x, const uint8_t* x_u8, float* s1, float* s2, int B, int C, int H, int W,
+                                const float* addk, void* stream);
+extern "C" int vst_block0_const(const vst_block_weights* w0, float* k16, void* stream);

@@ -669,9 +669,15 @@ static int revnet_forward_chunk(const vst_net_weights* w, const float* x, const 
     s[0] = (float*)workspace;
     s[1] = s[0] + (size_t)B * H * W * 16;
     float* tmp = s[1] + (size_t)B * H * W * 16;
-    int rc = x_u8 ? vst_pack_input_u8(x_u8, s[0], s[1], B, H, W, stream) : vst_pack_input(x, s[0], s[1], B, C_in, H, W, stream);
+    // forward block 0 has x2 = 0: F(0) is a per-channel constant that the pack kernel adds (fp32 diagnostic mode keeps
+    // the literal three convolutions)
+    const bool fold0 = precision == VST_PREC_BF16X3;
+    float* k16 = tmp;                                        // 16 floats at the head of the intermediates' scratch
+    int rc = fold0 ? vst_block0_const(&w->blocks[0], k16, stream) : VST_OK;
     if (rc) return rc;
-    for (int k = 0; k < VST_NUM_BLOCKS; ++k) {
+    rc = vst_pack_input_k(x, x_u8, s[0], s[1], B, x_u8 ? 3 : C_in, H, W, fold0 ? k16 : nullptr, stream);
+    if (rc) return rc;
+    for (int k = fold0 ? 1 : 0; k < VST_NUM_BLOCKS; ++k) {
         rc = vst_block_apply(&w->blocks[k], kBlockChannel[k], kBlockStride[k], +1, precision, s[k & 1], s[1 - (k & 1)],
                              tmp, B, H, W, stream);
         if (rc) return rc;

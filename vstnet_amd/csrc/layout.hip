@@ -11,7 +11,7 @@
 // x[B,C,H,W] -> s1 (view level 0, 16 channels, C..15 zero)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x, float* __restrict__ s1,
-                                                         int C, int H, int W) {
+                                                         int C, int H, int W, const float* __restrict__ addk) {
     const int xg = blockIdx.x * 64 + (threadIdx.x & 63);
     const int yg = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int b = blockIdx.z;
@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
     const float* src = x + (size_t)b * C * plane + (size_t)yg * W + xg;
     float v[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) v[c] = c < C ? src[c * plane] : 0.f;
+    for (int c = 0; c < 16; ++c) v[c] = (c < C ? src[c * plane] : 0.f) + (addk ? addk[c] : 0.f);
     float* dst = s1 + (size_t)b * plane * 16 + zc_offset(0, yg, xg, W >> 2);
 #pragma unroll
     for (int c = 0; c < 16; c += 4) *(float4*)(dst + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
@@ -44,16 +44,20 @@ __global__ __launch_bounds__(256) void unpack_output_kernel(const float* __restr
 // (image_transfer.py:217-218, video_transfer.py:212).  Frames cross PCIe as 3 bytes per pixel instead of 12.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_input_u8_kernel(const uint8_t* __restrict__ img, float* __restrict__ s1,
-                                                            int H, int W) {
+                                                            int H, int W, const float* __restrict__ addk) {
     const int xg = blockIdx.x * 64 + (threadIdx.x & 63);
     const int yg = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int b = blockIdx.z;
     if (xg >= W || yg >= H) return;
     const uint8_t* src = img + ((size_t)b * H * W + (size_t)yg * W + xg) * 3;
     float* dst = s1 + (size_t)b * H * W * 16 + zc_offset(0, yg, xg, W >> 2);
-    *(float4*)(dst) = make_float4((float)src[0] / 255.f, (float)src[1] / 255.f, (float)src[2] / 255.f, 0.f);
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    *(float4*)(dst + 4) = z; *(float4*)(dst + 8) = z; *(float4*)(dst + 12) = z;
+    float k[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) k[c] = addk ? addk[c] : 0.f;
+    *(float4*)(dst) = make_float4((float)src[0] / 255.f + k[0], (float)src[1] / 255.f + k[1], (float)src[2] / 255.f + k[2], k[3]);
+    *(float4*)(dst + 4) = make_float4(k[4], k[5], k[6], k[7]);
+    *(float4*)(dst + 8) = make_float4(k[8], k[9], k[10], k[11]);
+    *(float4*)(dst + 12) = make_float4(k[12], k[13], k[14], k[15]);
 }
 
 __global__ __launch_bounds__(256) void unpack_output_u8_kernel(const float* __restrict__ s1, uint8_t* __restrict__ img,
@@ -70,6 +74,35 @@ __global__ __launch_bounds__(256) void unpack_output_u8_kernel(const float* __re
         float t = c[k] * 255.f;
         t = t < 0.f ? 0.f : (t > 255.f ? 255.f : t);       // NaN falls through both compares like torch.clamp keeps NaN; byte() of it is 0
         dst[k] = (uint8_t)t;                               // truncation toward zero
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward block 0 sees x2 = 0 (injective_pad, RevResNet.py:212-214), so y1 = x1 + F(0) and F(0) is one constant per
+// channel: conv of zeros = bias, reflection padding of a constant map is the same constant, hence
+//   h1 = relu(b1),  h2 = relu(b2 + sum_taps W2 h1),  k = b3 + sum_taps W3 h2.
+// One tiny workgroup evaluates k (fp32, taps-major fp32 weight sections); the pack kernels add it, and the forward
+// pass skips block 0's three convolutions.
+// ------------------------------------------------------------------------------------------------
+__global__ void block0_const_kernel(const float* __restrict__ w2, const float* __restrict__ w3,
+                                    const float* __restrict__ b1, const float* __restrict__ b2,
+                                    const float* __restrict__ b3, float* __restrict__ k) {
+    __shared__ float h1[4], h2[4];
+    const int t = threadIdx.x;
+    if (t < 4) h1[t] = b1[t] > 0.f ? b1[t] : 0.f;
+    __syncthreads();
+    if (t < 4) {
+        float acc = b2[t];
+        for (int tap = 0; tap < 9; ++tap)
+            for (int ci = 0; ci < 4; ++ci) acc = fmaf(w2[(tap * 4 + ci) * 4 + t], h1[ci], acc);      // [tap][ci][co], co = 4
+        h2[t] = acc > 0.f ? acc : 0.f;
+    }
+    __syncthreads();
+    if (t < 16) {
+        float acc = b3[t];
+        for (int tap = 0; tap < 9; ++tap)
+            for (int ci = 0; ci < 4; ++ci) acc = fmaf(w3[(tap * 4 + ci) * 16 + t], h2[ci], acc);     // co = 16
+        k[t] = acc;
     }
 }
 
@@ -126,7 +159,8 @@ __global__ __launch_bounds__(256) void spread_gather_kernel(float* __restrict__ 
             const int X = t & 63, wave = t >> 6;
             const int wl = X >> 2, j = (X >> 1) & 1, jp = X & 1;
             const int xg = w0 * 4 + X;
-            for (int it = 0; it < 32; ++it) {
+#pragma unroll 8
+            for (int it = 0; it < 32; ++it) {                 // (unrolled: keeps 8 row-segment loads in flight when gathering)
                 const int combo = it * 4 + wave;          // (d32, Yl)
                 const int d = combo >> 2, Yl = combo & 3;
                 const int i = Yl >> 1, ip = Yl & 1;
@@ -140,6 +174,7 @@ __global__ __launch_bounds__(256) void spread_gather_kernel(float* __restrict__ 
             const int X = t & 31, dsel = (t >> 5) & 1, wave = t >> 6;
             const int wl = X >> 1, j = X & 1;
             const int xg = w0 * 2 + X;
+#pragma unroll 8
             for (int it = 0; it < 32; ++it) {
                 const int combo = (it * 4 + wave) * 2 + dsel;   // (d128, i)
                 const int d = combo >> 1, i = combo & 1;
@@ -224,15 +259,31 @@ int vst_pack_conv(const float* w, int cout, int cin, void* packed, void* stream)
     return VST_OK;
 }
 
-int vst_pack_input(const float* x, float* s1, float* s2, int B, int C, int H, int W, void* stream) {
-    if (!x || !s1 || !s2) return VST_E_ARG;
+int vst_pack_input_k(const float* x, const uint8_t* x_u8, float* s1, float* s2, int B, int C, int H, int W,
+                     const float* addk, void* stream) {
+    if ((!x && !x_u8) || !s1 || !s2) return VST_E_ARG;
     if (!vst_shape_ok(B, H, W) || C < 1 || C > 16) return VST_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(s2, 0, (size_t)B * H * W * 16 * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
-    pack_input_kernel<<<dim3((W + 63) / 64, (H + 3) / 4, B), 256, 0, st>>>(x, s1, C, H, W);
+    const dim3 grid((W + 63) / 64, (H + 3) / 4, B);
+    if (x_u8) pack_input_u8_kernel<<<grid, 256, 0, st>>>(x_u8, s1, H, W, addk);
+    else pack_input_kernel<<<grid, 256, 0, st>>>(x, s1, C, H, W, addk);
     VST_RETURN_IF_LAUNCH_FAILED();
     return VST_OK;
+}
+
+int vst_block0_const(const vst_block_weights* w0, float* k16, void* stream) {
+    if (!w0 || !k16) return VST_E_ARG;
+    block0_const_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const float*)w0->conv[1].packed, (const float*)w0->conv[2].packed,
+                                                           w0->conv[0].bias, w0->conv[1].bias, w0->conv[2].bias, k16);
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
+int vst_pack_input(const float* x, float* s1, float* s2, int B, int C, int H, int W, void* stream) {
+    if (!x) return VST_E_ARG;
+    return vst_pack_input_k(x, nullptr, s1, s2, B, C, H, W, nullptr, stream);
 }
 
 int vst_unpack_output(const float* s1, float* x, int B, int C, int H, int W, void* stream) {
@@ -244,14 +295,8 @@ int vst_unpack_output(const float* s1, float* x, int B, int C, int H, int W, voi
 }
 
 int vst_pack_input_u8(const uint8_t* frames_hwc, float* s1, float* s2, int B, int H, int W, void* stream) {
-    if (!frames_hwc || !s1 || !s2) return VST_E_ARG;
-    if (!vst_shape_ok(B, H, W)) return VST_E_SHAPE;
-    hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(s2, 0, (size_t)B * H * W * 16 * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
-    pack_input_u8_kernel<<<dim3((W + 63) / 64, (H + 3) / 4, B), 256, 0, st>>>(frames_hwc, s1, H, W);
-    VST_RETURN_IF_LAUNCH_FAILED();
-    return VST_OK;
+    if (!frames_hwc) return VST_E_ARG;
+    return vst_pack_input_k(nullptr, frames_hwc, s1, s2, B, 3, H, W, nullptr, stream);
 }
 
 int vst_unpack_output_u8(const float* s1, uint8_t* frames_hwc, int B, int H, int W, void* stream) {
