@@ -417,3 +417,41 @@ def test_masked_art_mode_with_resized_masks():
     assert_close(got, ref, 2e-3, "masked art z_cs", tol_max=2e-2)       # 128 channels, ~200-pixel regions: ill-conditioned
     with pytest.raises(ValueError):
         cWCT().transfer(net(xc.cuda()), net(xs.cuda()), cm, sm)
+
+
+# ------------------------------------------------------------------------------------------- more surface coverage
+def test_cached_style_equals_transfer_and_batch2_masked():
+    from models.cWCT import cWCT
+    net, sd, sp = make_net("photo")
+    cw = cWCT()
+    xc = synthetic_frames(2, 40, 56, seed=41).cuda()
+    xs = synthetic_frames(2, 32, 48, seed=42).cuda()
+    zc, zs = net(xc), net(xs)
+    ref = cw.transfer(zc, zs)
+    got = cw.transfer_with_stats(zc, cw.style_stats(zs))              # prefactored style (Cholesky cached)
+    assert_close(got, ref, 1e-6, "transfer_with_stats vs transfer")
+    one = cw.transfer_with_stats(zc, cw.style_stats(zs[:1]))          # one style for every frame of the batch
+    assert_close(one[0], ref[0], 1e-6, "single cached style, sample 0")
+    # masked, batch of 2 with different masks per sample, against the oracle
+    cm = np.stack([synthetic_mask(40, 56, 3, seed=7), synthetic_mask(40, 56, 4, seed=8)])
+    sm = np.stack([synthetic_mask(32, 48, 3, seed=9, speck=False), synthetic_mask(32, 48, 4, seed=10, speck=False)])
+    with torch.no_grad():
+        r = cpu_ref.transfer_seg(zc.cpu(), zs.cpu(), cm, sm)
+    assert_close(cw.transfer(zc, zs, cm, sm), r, 2e-4, "batch-2 masked transfer", tol_max=TOL)
+
+
+def test_input_forms_and_sample():
+    """non-contiguous / fp64 inputs are accepted like the reference's modules accept them; sample() runs"""
+    from models.cWCT import cWCT
+    net, sd, sp = make_net("photo")
+    x = synthetic_frames(1, 32, 32, seed=51)
+    base = net(x.cuda())
+    xt = x.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)      # same values, non-contiguous strides
+    assert not xt.is_contiguous()
+    assert torch.equal(net(xt.cuda()), base)
+    assert_close(net(x.double().cuda()), base, 1e-7, "fp64 input")
+    cw = cWCT(use_double=True)
+    out = cw.transfer(base.double(), base.double().flip(-1))
+    assert out.dtype == torch.float64 and out.shape == base.shape
+    xc, xs, xcs, cyc = net.sample(cWCT(), x, synthetic_frames(1, 32, 32, seed=52), "cuda")
+    assert xcs.shape == x.shape and cyc.shape == x.shape and torch.isfinite(xcs).all()

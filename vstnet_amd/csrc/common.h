@@ -45,6 +45,18 @@ __device__ __forceinline__ int reflect_clamp(int v, int n) {
     return v >= n ? n - 1 : v;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is per device: set it once per (kernel, device), not once per process
+static inline int vst_ensure_dynamic_lds(const void* kernel, int bytes, unsigned* done_mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 32 && (*done_mask >> dev) & 1u) return VST_OK;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 32) *done_mask |= 1u << dev;
+    return VST_OK;
+}
+
 static inline bool vst_shape_ok(int B, int H, int W) {
     return B > 0 && H >= 8 && W >= 8 && (H % 4) == 0 && (W % 4) == 0;
 }

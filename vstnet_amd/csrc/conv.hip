@@ -539,22 +539,14 @@ static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) 
     if constexpr (CIN >= 64 && COUT >= 64 && STRIDE == 1) {
         using C = PipeCfg<CIN, COUT>;
         auto kern = conv_pipe_kernel<CIN, COUT, IN_STATE, OUT_STATE>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-            if (e != hipSuccess) return (int)e;
-            attr_set = true;
-        }
+        static unsigned attr_done = 0;
+        if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)(C::LDS_BYTES), &attr_done)) return rc_;
         kern<<<dim3((a.Wout + 15) / 16, (a.Hout + 15) / 16, B), C::NTHR, C::LDS_BYTES, st>>>(a);
     } else {
         using C = ConvCfg<CIN, COUT, STRIDE>;
         auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, IN_STATE, OUT_STATE>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-            if (e != hipSuccess) return (int)e;
-            attr_set = true;
-        }
+        static unsigned attr_done = 0;
+        if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)(C::LDS_BYTES), &attr_done)) return rc_;
         const dim3 grid((a.Wout + C::TW - 1) / C::TW, (a.Hout + C::TH - 1) / C::TH, B * C::NCOT);
         kern<<<grid, 256, C::LDS_BYTES, st>>>(a);
     }

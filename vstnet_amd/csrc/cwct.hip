@@ -631,12 +631,8 @@ static int launch_apply_mfma(const float* x, float* y, long L, const float* affi
     if (wgs > 2048) wgs = 2048;
     const size_t lds = ((size_t)N * (N + 1) + N) * sizeof(float);
     auto kern = cwct_apply_mfma_kernel<NBLK, PXV>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned attr_done = 0;
+    if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)((int)lds), &attr_done)) return rc_;
     kern<<<dim3((unsigned)wgs), 256, lds, st>>>(x, y, L, affine, mask, label, ngroups);
     VST_RETURN_IF_LAUNCH_FAILED();
     return VST_OK;
@@ -716,13 +712,8 @@ int vst_cwct_factor(const double* content_stats, const double* const* style_stat
     a.n_styles = n_styles; a.alpha_c = alpha_c; a.eps = eps; a.N = N; a.affine = affine; a.info = info;
     const size_t lds = (size_t)N * N * 4 + (size_t)3 * N * 4 + 16;
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)cwct_factor_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           80 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned attr_done = 0;
+    if (int rc_ = vst_ensure_dynamic_lds((const void*)cwct_factor_kernel<8>, (int)(80 * 1024), &attr_done)) return rc_;
     switch (N) {
         case 16: cwct_factor_kernel<1><<<1, 256, lds, st>>>(a); break;
         case 32: cwct_factor_kernel<2><<<1, 256, lds, st>>>(a); break;
