@@ -455,3 +455,28 @@ def test_input_forms_and_sample():
     assert out.dtype == torch.float64 and out.shape == base.shape
     xc, xs, xcs, cyc = net.sample(cWCT(), x, synthetic_frames(1, 32, 32, seed=52), "cuda")
     assert xcs.shape == x.shape and cyc.shape == x.shape and torch.isfinite(xcs).all()
+
+
+def test_native_runner_matches_python_path(tmp_path):
+    """tools/vst_run (C++ host, C ABI only — no Python / torch in the process) == the drop-in classes, bit for bit"""
+    import subprocess
+    from models.cWCT import cWCT
+    from vstnet_amd.export import export_state_dict
+    if not os.path.exists(_lib.RUNNER_BIN):
+        _lib.build_runner()
+    for mode in ("photo", "art"):
+        net, sd, sp = make_net(mode)
+        hd = 16 if mode == "photo" else 64
+        export_state_dict(sd, str(tmp_path / "w.bin"), hd, sp)
+        g = torch.Generator().manual_seed(9)
+        c = torch.randint(0, 256, (1, 40, 64, 3), dtype=torch.uint8, generator=g)
+        s = torch.randint(0, 256, (1, 32, 48, 3), dtype=torch.uint8, generator=g)
+        c.numpy().tofile(tmp_path / "c.rgb"); s.numpy().tofile(tmp_path / "s.rgb")
+        r = subprocess.run([_lib.RUNNER_BIN, str(tmp_path / "w.bin"), str(tmp_path / "c.rgb"), "40", "64",
+                            str(tmp_path / "s.rgb"), "32", "48", str(tmp_path / "o.rgb")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr + r.stdout
+        got = np.fromfile(tmp_path / "o.rgb", dtype=np.uint8).reshape(40, 64, 3)
+        cw = cWCT()
+        zc, zs = net.forward_u8(c.cuda()), net.forward_u8(s.cuda())
+        ref = net.inverse_u8(cw.transfer_with_stats(zc, cw.style_stats(zs)))[0].cpu().numpy()
+        assert np.array_equal(got, ref), mode

@@ -61,6 +61,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+RUNNER_SRC = os.path.join(REPO_DIR, "tools", "vst_run.cpp")
+RUNNER_BIN = os.path.join(REPO_DIR, "tools", "vst_run")
+
+
+def build_runner(force: bool = False) -> str:
+    """Compile the native (no Python / torch) host runner against the shared library."""
+    if not force and os.path.exists(RUNNER_BIN) and os.path.getmtime(RUNNER_BIN) >= max(os.path.getmtime(RUNNER_SRC),
+                                                                                       os.path.getmtime(LIB_PATH)):
+        return RUNNER_BIN
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O2", "--offload-arch=gfx950", "-std=c++17", "-I", os.path.join(REPO_DIR, "include"), RUNNER_SRC,
+           "-L", PKG_DIR, "-lvstnet_hip", "-Wl,-rpath," + PKG_DIR, "-Wl,-rpath,$ORIGIN/../vstnet_amd", "-o", RUNNER_BIN]
+    subprocess.run(cmd, check=True)
+    return RUNNER_BIN
+
+
 _lib = None
 
 
