@@ -31,6 +31,8 @@ def build_parser():
     p.add_argument('--style_seg', type=str, default=None)
     p.add_argument('--auto_seg', action='store_true', default=False)
     p.add_argument('--synthetic_weights', action='store_true', default=False)
+    # the delldu fork's post-process (project/image_style/vstnet.py:189-220): keep the content's Lab luminance
+    p.add_argument('--preserve_luminance', action='store_true', default=False)
     return p
 
 
@@ -52,7 +54,8 @@ def build_network(mode, ckpoint, synthetic, device):
     return net.to(device).eval()
 
 
-def stylize(net, cwct, content_img, style_img, content_seg=None, style_seg=None, alpha_c=None, device="cuda"):
+def stylize(net, cwct, content_img, style_img, content_seg=None, style_seg=None, alpha_c=None, device="cuda",
+            preserve_luminance=False):
     """image_transfer.py:172-201 with the uint8 frame edge on the device; returns uint8 [H,W,3] numpy."""
     with torch.no_grad():
         z_c = net.forward_u8(to_tensor_u8(content_img).to(device))
@@ -62,7 +65,12 @@ def stylize(net, cwct, content_img, style_img, content_seg=None, style_seg=None,
             z_cs = cwct.interpolation(z_c, styl_feat_list=[z_s], alpha_s_list=[1.0], alpha_c=alpha_c)
         else:
             z_cs = cwct.transfer(z_c, z_s, content_seg, style_seg)
-        return net.inverse_u8(z_cs)[0].cpu().numpy()
+        if not preserve_luminance:
+            return net.inverse_u8(z_cs)[0].cpu().numpy()
+        from vstnet_amd.color import luminance_transfer
+        content = to_tensor_u8(content_img).to(device).permute(0, 3, 1, 2).float().div(255.0)
+        out = luminance_transfer(content, net(z_cs, forward=False))
+        return out[0].mul(255.0).clamp(0, 255).byte().permute(1, 2, 0).cpu().numpy()
 
 
 def main(argv=None):
@@ -84,7 +92,7 @@ def main(argv=None):
         content_seg = load_segment(args.content_seg, content.size)[None, ...]
         style_seg = load_segment(args.style_seg, style.size)[None, ...]
 
-    out = stylize(net, cwct, content, style, content_seg, style_seg, args.alpha_c, device)
+    out = stylize(net, cwct, content, style, content_seg, style_seg, args.alpha_c, device, args.preserve_luminance)
     cn, sn = os.path.basename(args.content), os.path.basename(args.style)
     path = os.path.join(args.out_dir, "%s_%s.png" % (cn.split(".")[0], sn.split(".")[0]))
     Image.fromarray(out).save(path, quality=100)

@@ -82,6 +82,10 @@ int vst_unpack_output(const float* s1, float* x, int B, int C, int H, int W, voi
  * and back with mul(255).clamp(0,255).byte() truncation (image_transfer.py:217-218) */
 int vst_pack_input_u8(const uint8_t* frames_hwc, float* s1, float* s2, int B, int H, int W, void* stream);
 int vst_unpack_output_u8(const float* s1, uint8_t* frames_hwc, int B, int H, int W, void* stream);
+/* Lab luminance-preserving post-process of the fork: out = lab2rgb(cat(L(content),
+ * ab(clamp(stylized,0,1)))), all three [B,3,H,W] fp32 in [0,1]; any H, W >= 1 (no multiple-of-4 requirement).
+ * project/image_style/vstnet.py:189-220, project/image_style/color.py:18-113.  out may alias stylized. */
+int vst_lab_luminance(const float* content, const float* stylized, float* out, int B, int H, int W, void* stream);
 /* merge + "spread" (unsqueeze x sp_steps), RevResNet.py:139-144 -> z[B,32,H,W] (sp=2) or [B,128,H/2,W/2] (sp=1) */
 int vst_spread(const float* s1, const float* s2, float* z, int B, int H, int W, int sp_steps, void* stream);
 /* inverse of vst_spread: squeeze x sp_steps + split, RevResNet.py:148-154 */

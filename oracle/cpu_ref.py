@@ -347,3 +347,57 @@ class SegReMappingLoop:
         for i, cur in enumerate(labels):
             out[seg == cur] = new[i]
         return out
+
+
+# --------------------------------------------------------------------------- Lab luminance post-process (8(f) rank 4)
+def _rgb2lab(rgb):
+    """project/image_style/color.py:18-53,94-104 — sRGB [0,1] -> Lab rescaled to [-1,1] (clamped).  Same arithmetic
+    order as the reference (mask-multiply selects, left-to-right sums)."""
+    mask = (rgb > 0.04045).float()
+    rgb = (((rgb + 0.055) / 1.055) ** 2.4) * mask + rgb / 12.92 * (1.0 - mask)
+    r, g, b = rgb[:, 0], rgb[:, 1], rgb[:, 2]
+    x = 0.412453 * r + 0.357580 * g + 0.180423 * b
+    y = 0.212671 * r + 0.715160 * g + 0.072169 * b
+    z = 0.019334 * r + 0.119193 * g + 0.950227 * b
+    xyz = torch.stack((x, y, z), dim=1)
+    sc = torch.tensor((0.95047, 1.0, 1.08883))[None, :, None, None]
+    t = xyz / sc
+    mask = (t > 0.008856).float()
+    f = t ** (1.0 / 3.0) * mask + (7.787 * t + 16.0 / 116.0) * (1.0 - mask)
+    L = 116.0 * f[:, 1] - 16.0
+    a = 500.0 * (f[:, 0] - f[:, 1])
+    b = 200.0 * (f[:, 1] - f[:, 2])
+    lab = torch.stack((L, a, b), dim=1)
+    out = torch.cat(((lab[:, 0:1] - 50.0) / 50.0, lab[:, 1:3] / 110.0), dim=1)
+    return out.clamp(-1.0, 1.0)
+
+
+def _lab2rgb(lab_rs):
+    """project/image_style/color.py:56-91,107-113."""
+    L = lab_rs[:, 0] * 50.0 + 50.0
+    a = lab_rs[:, 1] * 110.0
+    b = lab_rs[:, 2] * 110.0
+    y = (L + 16.0) / 116.0
+    x = (a / 500.0) + y
+    z = torch.max(torch.tensor((0,)), y - (b / 200.0))
+    out = torch.stack((x, y, z), dim=1)
+    mask = (out > 0.2068966).float()
+    out = (out ** 3.0) * mask + (out - 16.0 / 116.0) / 7.787 * (1.0 - mask)
+    xyz = out * torch.tensor((0.95047, 1.0, 1.08883))[None, :, None, None]
+    X, Y, Z = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    r = 3.24048134 * X - 1.53715152 * Y - 0.49853633 * Z
+    g = -0.96925495 * X + 1.87599 * Y + 0.04155593 * Z
+    bl = 0.05564664 * X - 0.20404134 * Y + 1.05731107 * Z
+    rgb = torch.stack((r, g, bl), dim=1)
+    rgb = torch.max(rgb, torch.zeros_like(rgb))
+    mask = (rgb > 0.0031308).float()
+    rgb = (1.055 * (rgb ** (1.0 / 2.4)) - 0.055) * mask + 12.92 * rgb * (1.0 - mask)
+    return rgb.clamp(0.0, 1.0)
+
+
+def luminance_transfer(content, stylized):
+    """project/image_style/vstnet.py:189-220 — keep the content's L channel, take a/b from the (clamped) stylised
+    image: lab2rgb(cat(L(content), ab(stylized)))."""
+    lab_c = _rgb2lab(content)
+    lab_o = _rgb2lab(stylized.clamp(0.0, 1.0))        # the fork's decoder clamps its output (vstnet.py:322)
+    return _lab2rgb(torch.cat((lab_c[:, 0:1], lab_o[:, 1:3]), dim=1))

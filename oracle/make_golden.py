@@ -240,6 +240,20 @@ def main():
     save("cwct_jitter", conv=conv, L=Lr, tries=tries, ones4_L=Ls_ref, ones4_tries=t2,
          neg_in=neg, neg_L=Ln_ref, neg_tries=t3)
 
+    # ------------------------------------------------------------------ Lab luminance post-process (fork's project/ package)
+    print("lab")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("reference_color", os.path.join(REF, "project", "image_style", "color.py"))
+    color = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(color)
+    cimg = synthetic_frames(2, 24, 40, seed=61)
+    simg = (synthetic_frames(2, 24, 40, seed=62) * 1.3 - 0.15).clamp(0, 1)       # decoder output, clamped like the fork's
+    lab_c, lab_o = color.rgb2lab(cimg), color.rgb2lab(simg)
+    out = color.lab2rgb(torch.cat((lab_c[:, 0:1], lab_o[:, 1:3]), dim=1))
+    check("rgb2lab", cpu_ref._rgb2lab(cimg), lab_c, 0.0)
+    check("luminance_transfer", cpu_ref.luminance_transfer(cimg, simg), out, 0.0)
+    save("lab", content=cimg, stylized=simg, lab_content=lab_c, out=out)
+
     # ------------------------------------------------------------------ config 1: photo 256x256 stylisation
     print("config-1 (photo 256x256, image_transfer.py call sequence)")
     net, sd, sp = build_ref_net(ref_rev, "photo")

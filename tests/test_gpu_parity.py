@@ -480,3 +480,45 @@ def test_native_runner_matches_python_path(tmp_path):
         zc, zs = net.forward_u8(c.cuda()), net.forward_u8(s.cuda())
         ref = net.inverse_u8(cw.transfer_with_stats(zc, cw.style_stats(zs)))[0].cpu().numpy()
         assert np.array_equal(got, ref), mode
+
+
+def test_lab_luminance_postprocess(L, golden):
+    """vst_lab_luminance against the golden minted from the fork's color.py and the oracle
+    (fp32 pointwise; pow() differs by an ulp or two between libm and the device -> 1e-5 absolute on [0,1])."""
+    from vstnet_amd.color import luminance_transfer
+    g = golden("lab")
+    c, s = T(g["content"]), T(g["stylized"])
+    got = luminance_transfer(c.cuda(), s.cuda()).cpu()
+    assert float((got - T(g["out"])).abs().max()) < 1e-5
+    # unclamped decoder output, odd sizes (scalar path), batch > 1, in-place over the stylised image
+    for (B, H, W, seed) in ((1, 7, 13, 3), (3, 33, 50, 4), (2, 64, 64, 5)):
+        c = synthetic_frames(B, 8 * ((H + 7) // 8), 8 * ((W + 7) // 8), seed=seed)[:, :, :H, :W].contiguous()
+        s = (synthetic_frames(B, 8 * ((H + 7) // 8), 8 * ((W + 7) // 8), seed=seed + 50)[:, :, :H, :W] * 1.6 - 0.3).contiguous()
+        ref = cpu_ref.luminance_transfer(c, s)
+        sg = s.cuda()
+        got = luminance_transfer(c.cuda(), sg, out=sg).cpu()
+        assert got.shape == ref.shape and float((got - ref).abs().max()) < 1e-5, (B, H, W)
+    # exact edge values: black, white, the sRGB knee
+    c = torch.tensor([0.0, 1.0, 0.04045, 0.5]).view(1, 1, 1, 4).expand(1, 3, 1, 4).contiguous()
+    s = torch.tensor([1.0, 0.0, 0.04045, 0.25]).view(1, 1, 1, 4).expand(1, 3, 1, 4).contiguous()
+    assert float((luminance_transfer(c.cuda(), s.cuda()).cpu() - cpu_ref.luminance_transfer(c, s)).abs().max()) < 1e-5
+    with pytest.raises(RuntimeError):
+        luminance_transfer(c, s)                                        # no CPU path
+    assert L.vst_lab_luminance(None, None, None, 1, 4, 4, None) == -1
+
+
+def test_image_transfer_script_preserve_luminance(tmp_path):
+    from PIL import Image
+    import image_transfer
+    c = _png(tmp_path / "c.png", 48, 68, 11)
+    s = _png(tmp_path / "s.png", 40, 40, 12)
+    out = image_transfer.main(["--content", str(tmp_path / "c.png"), "--style", str(tmp_path / "s.png"),
+                               "--out_dir", str(tmp_path / "o"), "--synthetic_weights", "--preserve_luminance"])
+    got = np.asarray(Image.open(out))
+    sd = synthetic_state_dict(1234)
+    tt = lambda a: T(np.ascontiguousarray(a)).permute(2, 0, 1)[None].float().div(255)
+    with torch.no_grad():
+        sty = cpu_ref.stylize(tt(c), tt(s), sd, 2)[3]
+        ref = cpu_ref.to_uint8(cpu_ref.luminance_transfer(tt(c), sty))[0].numpy()
+    d = np.abs(got.astype(int) - ref.astype(int))
+    assert got.shape == ref.shape and d.max() <= 1 and (d > 0).mean() < 2e-2

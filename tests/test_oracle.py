@@ -124,3 +124,18 @@ def test_config1(golden):
     close(sty, T(g["stylized"]), 5e-5)
     diff = (cpu_ref.to_uint8(sty).int() - T(g["stylized_u8"]).int()).abs()
     assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 1e-3
+
+
+def test_lab_luminance(golden):
+    """the fork's Lab post-process (project/image_style/color.py, vstnet.py:189-220): bit-identical restatement"""
+    g = golden("lab")
+    c, s = T(g["content"]), T(g["stylized"])
+    assert torch.equal(cpu_ref._rgb2lab(c), T(g["lab_content"]))
+    out = cpu_ref.luminance_transfer(c, s)
+    assert torch.equal(out, T(g["out"]))
+    # properties: idempotent on its own output's luminance; identity when stylized == content (up to the Lab clamp)
+    same = cpu_ref.luminance_transfer(c, c)
+    assert float((same - c).abs().max()) < 2e-3
+    gray = c.mean(1, keepdim=True).expand(-1, 3, -1, -1)
+    lab = cpu_ref._rgb2lab(gray)
+    assert float(lab[:, 1:].abs().max()) < 2e-3                       # greys have no chroma

@@ -27,7 +27,7 @@ EXPORTS = [
     "vst_spread", "vst_gather", "vst_block_tmp_bytes", "vst_block_apply",
     "vst_pass_workspace_bytes", "vst_revnet_forward", "vst_revnet_inverse",
     "vst_cwct_stats_workspace_bytes", "vst_cwct_stats", "vst_cwct_factor", "vst_cwct_apply",
-    "vst_cwct_prefactor", "vst_profile_begin", "vst_profile_end",
+    "vst_cwct_prefactor", "vst_profile_begin", "vst_profile_end", "vst_lab_luminance",
 ]
 
 
@@ -99,6 +99,7 @@ def lib() -> C.CDLL:
         "vst_unpack_output": (i, [vp, vp, i, i, i, i, vp]),
         "vst_pack_input_u8": (i, [vp, vp, vp, i, i, i, vp]),
         "vst_unpack_output_u8": (i, [vp, vp, i, i, i, vp]),
+        "vst_lab_luminance": (i, [vp, vp, vp, i, i, i, vp]),
         "vst_revnet_forward_u8": (i, [C.POINTER(NetWeights), vp, vp, vp, i, i, i, i, i, vp]),
         "vst_revnet_inverse_u8": (i, [C.POINTER(NetWeights), vp, vp, vp, i, i, i, i, i, vp]),
         "vst_spread": (i, [vp, vp, vp, i, i, i, i, vp]),
