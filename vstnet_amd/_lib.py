@@ -12,7 +12,7 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "libvstnet_hip.so")
+LIB_PATH = os.environ.get("VSTNET_HIP_LIB") or os.path.join(PKG_DIR, "libvstnet_hip.so")   # override: A/B builds
 SOURCES = sorted(glob.glob(os.path.join(PKG_DIR, "csrc", "*.hip")))
 HEADERS = sorted(glob.glob(os.path.join(PKG_DIR, "csrc", "*.h"))) + [os.path.join(REPO_DIR, "include", "vstnet.h")]
 

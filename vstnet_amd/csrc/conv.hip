@@ -30,7 +30,24 @@ struct ConvArgs {
     size_t in_img_stride;        // floats per image
     size_t out_img_stride;
     float sign;                  // OUT_STATE: out += sign * (conv + bias)
+    int tiles_x, tiles_y, tiles_total;   // 1-D grid of round_up(tiles_total, 8) workgroups, see xcd_tile()
 };
+
+// Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2.  Give XCD k the contiguous
+// (row-major) range of tiles [k*per, (k+1)*per) so that tiles sharing a halo also share an L2.
+#ifndef VST_XCD_REMAP
+#define VST_XCD_REMAP 1
+#endif
+__device__ __forceinline__ bool xcd_tile(const ConvArgs& a, int& bx, int& by, int& bz) {
+    const int g = blockIdx.x, per = gridDim.x >> 3;
+    const int n = VST_XCD_REMAP ? (g & 7) * per + (g >> 3) : g;
+    if (n >= a.tiles_total) return false;
+    bx = n % a.tiles_x;
+    const int r = n / a.tiles_x;
+    by = r % a.tiles_y;
+    bz = r / a.tiles_y;
+    return true;
+}
 
 template <int CIN, int COUT, int STRIDE>
 struct ConvCfg {
@@ -148,8 +165,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
-    const int tx0 = blockIdx.x * C::TW, ty0 = blockIdx.y * C::TH;
-    const int b = blockIdx.z / C::NCOT, co0 = (blockIdx.z % C::NCOT) * C::NT;
+    int bx, by, bz;
+    if (!xcd_tile(a, bx, by, bz)) return;
+    const int tx0 = bx * C::TW, ty0 = by * C::TH;
+    const int b = bz / C::NCOT, co0 = (bz % C::NCOT) * C::NT;
 
     const float* const in_img = a.in + (size_t)b * a.in_img_stride;
     const PackedConvLayout PL = packed_conv_layout(COUT, CIN);
@@ -313,7 +332,9 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
-    const int tx0 = blockIdx.x * 16, ty0 = blockIdx.y * 16, b = blockIdx.z;
+    int bx, by, b;
+    if (!xcd_tile(a, bx, by, b)) return;
+    const int tx0 = bx * 16, ty0 = by * 16;
     const float* const in_img = a.in + (size_t)b * a.in_img_stride;
     float* const out_img = a.out + (size_t)b * a.out_img_stride;
     const PackedConvLayout PL = packed_conv_layout(COUT, CIN);
@@ -541,14 +562,18 @@ static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) 
         auto kern = conv_pipe_kernel<CIN, COUT, IN_STATE, OUT_STATE>;
         static unsigned attr_done = 0;
         if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)(C::LDS_BYTES), &attr_done)) return rc_;
-        kern<<<dim3((a.Wout + 15) / 16, (a.Hout + 15) / 16, B), C::NTHR, C::LDS_BYTES, st>>>(a);
+        ConvArgs t = a;
+        t.tiles_x = (a.Wout + 15) / 16; t.tiles_y = (a.Hout + 15) / 16; t.tiles_total = t.tiles_x * t.tiles_y * B;
+        kern<<<dim3((t.tiles_total + 7) / 8 * 8), C::NTHR, C::LDS_BYTES, st>>>(t);
     } else {
         using C = ConvCfg<CIN, COUT, STRIDE>;
         auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, IN_STATE, OUT_STATE>;
         static unsigned attr_done = 0;
         if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)(C::LDS_BYTES), &attr_done)) return rc_;
-        const dim3 grid((a.Wout + C::TW - 1) / C::TW, (a.Hout + C::TH - 1) / C::TH, B * C::NCOT);
-        kern<<<grid, 256, C::LDS_BYTES, st>>>(a);
+        ConvArgs t = a;
+        t.tiles_x = (a.Wout + C::TW - 1) / C::TW; t.tiles_y = (a.Hout + C::TH - 1) / C::TH;
+        t.tiles_total = t.tiles_x * t.tiles_y * B * C::NCOT;
+        kern<<<dim3((t.tiles_total + 7) / 8 * 8), 256, C::LDS_BYTES, st>>>(t);
     }
     if (timed) { (void)hipEventRecord(g_prof_ev[2 * g_prof_count + 1], st); ++g_prof_count; }
     VST_RETURN_IF_LAUNCH_FAILED();
