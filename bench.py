@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--recompute-style", action="store_true", help="re-encode + re-factor the style every frame "
                     "(the reference's video loop, video_transfer.py:195) instead of caching it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-pipeline", type=int, default=0, metavar="FRAMES", help="also time FRAMES uint8 frames that "
+                    "start and end in host memory through vstnet_amd.pipeline.FramePipeline (PCIe-inclusive rate; "
+                    "reported as an extra field, never as `value`)")
     ap.add_argument("--streams", type=int, default=2, help="independent frames in flight per GPU, one HIP stream each "
                     "(the MFMA-bound and the HBM-bound kernels of different frames overlap); 1 = strictly sequential")
     args = ap.parse_args()
@@ -172,6 +175,21 @@ def main():
                                "frac": round(frame_gbs / HBM_PEAK_GBS, 4), "per": "GPU"},
     }
 
+    if args.host_pipeline > 0 and not args.masked and fpg == 1:
+        # PCIe-inclusive: uint8 frames in pageable host memory -> pinned ring -> H2D -> encode/cWCT/decode -> D2H -> host
+        from vstnet_amd.pipeline import FramePipeline
+        with torch.no_grad():
+            host = [(content[0].permute(1, 2, 0) * 255).byte().contiguous().cpu().numpy()] * 4
+            pipe = FramePipeline(net, lambda z, i: cw.transfer_with_stats(z, s_stats), Hf, Wf, device=dev, depth=4,
+                                 compute_streams=max(1, args.streams))
+            pipe.run((host[i % 4] for i in range(8)), lambda i, a: None)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pipe.run((host[i % 4] for i in range(args.host_pipeline)), lambda i, a: None)
+            dt = time.perf_counter() - t0
+        rec["host_pipeline"] = {"value": round(args.host_pipeline / dt, 2), "unit": "frames/s", "per": "GPU",
+                                "frames": args.host_pipeline, "note": "uint8 HWC frames from and to host memory, pinned "
+                                "ring buffers, H2D/compute/D2H overlapped; PCIe-inclusive, not `value`"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         rec["cpu_baseline"] = cpu_baseline(sd, sp, Hf, Wf)
     if rank == 0:

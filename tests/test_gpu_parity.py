@@ -522,3 +522,44 @@ def test_image_transfer_script_preserve_luminance(tmp_path):
         ref = cpu_ref.to_uint8(cpu_ref.luminance_transfer(tt(c), sty))[0].numpy()
     d = np.abs(got.astype(int) - ref.astype(int))
     assert got.shape == ref.shape and d.max() <= 1 and (d > 0).mean() < 2e-2
+
+
+def test_frame_pipeline_matches_sequential():
+    """the overlapped pinned-buffer frame loop returns exactly what the one-frame-at-a-time
+    loop returns (plain, masked, and with a decode hook that writes another size), in order."""
+    from models.cWCT import cWCT
+    from vstnet_amd.pipeline import FramePipeline, AsyncSink, prefetch
+    net, sd, sp = make_net("photo")
+    cw = cWCT()
+    H, W, N = 64, 96, 9
+    frames = [(synthetic_frames(1, H, W, seed=100 + i)[0].permute(1, 2, 0) * 255).byte().numpy() for i in range(N)]
+    style = (synthetic_frames(1, 48, 64, seed=7)[0].permute(1, 2, 0) * 255).byte()[None].cuda()
+    cmask, smask = synthetic_mask(H, W, 3, seed=1)[None], synthetic_mask(48, 64, 3, seed=2)[None]
+    with torch.no_grad():
+        z_s = net.forward_u8(style)
+        stats = cw.style_stats(z_s)
+        for masked in (False, True):
+            tf = (lambda z, i: cw.transfer(z, z_s, cmask, smask)) if masked else (lambda z, i: cw.transfer_with_stats(z, stats))
+            ref = [net.inverse_u8(tf(net.forward_u8(T(f)[None].cuda()), i))[0].cpu().numpy() for i, f in enumerate(frames)]
+            got = {}
+            sink = AsyncSink(lambda i, a: got.__setitem__(i, a))
+            pipe = FramePipeline(net, tf, H, W, depth=3, compute_streams=2)
+            assert pipe.run(prefetch(iter(frames), ahead=2), sink, start_index=5) == N
+            sink.close()
+            assert sorted(got) == list(range(5, 5 + N))
+            for i in range(N):
+                assert np.array_equal(got[5 + i], ref[i]), (masked, i)
+        # decode hook: half-size output
+        def decode(z):
+            y = net(z, forward=False)[:, :, ::2, ::2]
+            return y.mul(255).clamp(0, 255).byte().permute(0, 2, 3, 1).contiguous()
+        tf = lambda z, i: cw.transfer_with_stats(z, stats)
+        ref = [decode(tf(net.forward_u8(T(f)[None].cuda()), 0))[0].cpu().numpy() for f in frames[:4]]
+        out = []
+        pipe = FramePipeline(net, tf, H, W, depth=2, compute_streams=1, decode=decode, out_height=H // 2, out_width=W // 2)
+        pipe.run(frames[:4], lambda i, a: out.append(a.copy()))
+        assert all(np.array_equal(a, b) for a, b in zip(out, ref))
+        with pytest.raises(ValueError):
+            pipe.run([frames[0][:32]], lambda i, a: None)
+    with pytest.raises(ValueError):
+        FramePipeline(net, tf, 30, 32)

@@ -3,7 +3,8 @@
 160-214) on the MI355X HIP path.
 
 Differences that do not change pixels: the style is encoded and factored ONCE (the reference re-encodes it for
-every frame, :195); frames move as uint8 and are quantised on the device.  The writer-size quirk of the
+every frame, :195); frames move as uint8 through pinned ring buffers and are quantised on the device; decode/resize,
+H2D, compute, D2H and encode overlap (vstnet_amd/pipeline.py) instead of running one after the other.  The writer-size quirk of the
 reference is kept (:83-86: video_width is overwritten before it scales video_height, so a 1920x1080 clip at
 --max_size 1280 is written at 1280x1080 while frames are stylised at 1280x720).
 --video may be a directory of frames (always works) or a video file (needs cv2, optional).  Output: an .mp4 if
@@ -20,6 +21,7 @@ from PIL import Image
 
 from image_transfer import build_network
 from utils.utils import img_resize, load_segment, to_tensor_u8
+from vstnet_amd.pipeline import FramePipeline, AsyncSink, prefetch
 from vstnet_amd.sharding import shard_range
 
 IMG_EXT = ('.jpg', '.jpeg', '.png', '.ppm', '.bmp')
@@ -40,6 +42,8 @@ def build_parser():
     p.add_argument('--auto_seg', action='store_true', default=False)
     p.add_argument('--synthetic_weights', action='store_true', default=False)
     p.add_argument('--shard', type=str, default="0/1")
+    p.add_argument('--depth', type=int, default=4, help="pinned ring slots (frames queued ahead of the one being written)")
+    p.add_argument('--streams', type=int, default=2, help="frames in flight on the card")
     return p
 
 
@@ -101,28 +105,43 @@ def main(argv=None):
         frame_dir = os.path.join(args.out_dir, name)
         os.makedirs(frame_dir, exist_ok=True)
 
-    for i in range(lo, hi):
-        content = img_resize(frames[i], args.max_size, down_scale=net.down_scale)
-        content_seg = load_segment(args.content_seg, content.size)[None, ...] if masked else None
-        with torch.no_grad():
-            z_c = net.forward_u8(to_tensor_u8(content).to(device))
-            if args.alpha_c is not None and not masked:
-                assert 0.0 <= args.alpha_c <= 1.0
-                z_cs = cwct.interpolation(z_c, styl_feat_list=[z_s], alpha_s_list=[1.0], alpha_c=args.alpha_c)
-            elif masked:
-                z_cs = cwct.transfer(z_c, z_s, content_seg, style_seg)
-            else:
-                z_cs = cwct.transfer_with_stats(z_c, s_stats)
-            if (content.size[0], content.size[1]) == (video_width, video_height):
-                out = net.inverse_u8(z_cs)[0].cpu().numpy()
-            else:       # transforms.Resize((video_height, video_width), BICUBIC) on the float tensor, then quantise
-                sty = net(z_cs, forward=False)
-                sty = F.interpolate(sty, size=(video_height, video_width), mode="bicubic", align_corners=False, antialias=True)
-                out = sty[0].mul(255).clamp(0, 255).byte().permute(1, 2, 0).cpu().numpy()
+    def write(i, out):
         if writer is not None:
             writer.write(out[..., ::-1])
         else:
             Image.fromarray(out).save(os.path.join(frame_dir, "%05d.png" % i))
+
+    if hi > lo:
+        first = img_resize(frames[lo], args.max_size, down_scale=net.down_scale)
+        content_seg = load_segment(args.content_seg, first.size)[None, ...] if masked else None
+        cw_, ch_ = first.size
+
+        def transform(z_c, i):
+            if args.alpha_c is not None and not masked:
+                assert 0.0 <= args.alpha_c <= 1.0
+                return cwct.interpolation(z_c, styl_feat_list=[z_s], alpha_s_list=[1.0], alpha_c=args.alpha_c)
+            if masked:
+                return cwct.transfer(z_c, z_s, content_seg, style_seg)
+            return cwct.transfer_with_stats(z_c, s_stats)
+
+        decode = None
+        if (cw_, ch_) != (video_width, video_height):
+            def decode(z_cs):   # transforms.Resize((video_height, video_width), BICUBIC) on the float tensor, then quantise
+                sty = net(z_cs, forward=False)
+                sty = F.interpolate(sty, size=(video_height, video_width), mode="bicubic", align_corners=False, antialias=True)
+                return sty.mul(255).clamp(0, 255).byte().permute(0, 2, 3, 1).contiguous()
+
+        def source():        # decode + resize in a background thread (img_resize: utils/utils.py:90-101)
+            for i in range(lo, hi):
+                yield np.asarray(img_resize(frames[i], args.max_size, down_scale=net.down_scale), dtype=np.uint8)
+
+        pipe = FramePipeline(net, transform, ch_, cw_, device=device, depth=args.depth, compute_streams=args.streams,
+                             decode=decode, out_height=video_height, out_width=video_width)
+        sink = AsyncSink(write)
+        try:
+            pipe.run(prefetch(source(), ahead=args.depth), sink, start_index=lo)
+        finally:
+            sink.close()
     if writer is not None:
         writer.release()
     print("Save stylized video at %s" % (frame_dir or args.out_dir))
