@@ -563,3 +563,4 @@ def test_frame_pipeline_matches_sequential():
             pipe.run([frames[0][:32]], lambda i, a: None)
     with pytest.raises(ValueError):
         FramePipeline(net, tf, 30, 32)
+
