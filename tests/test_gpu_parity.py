@@ -564,3 +564,85 @@ def test_frame_pipeline_matches_sequential():
     with pytest.raises(ValueError):
         FramePipeline(net, tf, 30, 32)
 
+
+
+# ------------------------------------------------------------------------------------------- BASELINE configs 3-5 at full size
+def _cov(m):
+    d = m - m.mean(-1, keepdim=True)
+    return d @ d.t() / (m.shape[1] - 1)
+
+
+def test_full_size_config3_art_batch4():
+    """config 3's per-GPU share: artistic mode, 4 frames of 1024x1024 in one batch.  Properties: every frame of the
+    batch equals the same frame run alone (bit for bit), the pass inverts, the code takes the style's moments."""
+    from models.cWCT import cWCT
+    net, sd, sp = make_net("art")
+    cw = cWCT()
+    x = synthetic_frames(4, 1024, 1024, seed=3).cuda()
+    xs = synthetic_frames(1, 1024, 1024, seed=1).cuda()
+    with torch.no_grad():
+        z = net(x)
+        assert z.shape == (4, 128, 512, 512)
+        z1 = net(x[2:3])
+        assert torch.equal(z[2:3], z1)
+        assert float((net(z, forward=False) - x).abs().max()) < 5e-6
+        stats = cw.style_stats(net(xs))
+        zcs = cw.transfer_with_stats(z, stats)
+        zs = net(xs)[0].reshape(128, -1).double()
+        for b in (0, 3):
+            a = zcs[b].reshape(128, -1).double()
+            assert float((a.mean(-1) - zs.mean(-1)).abs().max()) < 1e-5 * max(1.0, float(zs.mean(-1).abs().max()))
+            assert float((_cov(a) - _cov(zs)).abs().max() / _cov(zs).abs().max()) < 1e-4
+        sty = net(zcs, forward=False)
+        assert torch.isfinite(sty).all() and sty.shape == x.shape
+
+
+def test_full_size_config4_4096():
+    """config 4: one 4096x4096 photorealistic image on one GPU (2 GiB of state per half; the pass runs in sub-batches
+    sized for the Infinity Cache).  Properties: invertibility, style moments, and the top-left 512x512 of the code
+    equals the code of the top-left 640x640 crop there (receptive field 30 blocks x 3 convs = 90 px < 128)."""
+    from models.cWCT import cWCT
+    net, sd, sp = make_net("photo")
+    cw = cWCT()
+    x = synthetic_frames(1, 4096, 4096, seed=11).cuda()
+    xs = synthetic_frames(1, 1024, 1024, seed=1).cuda()
+    with torch.no_grad():
+        z = net(x)
+        assert float((net(z, forward=False) - x).abs().max()) < 5e-6
+        zc = net(x[:, :, :1024, :1024].contiguous())
+        d = (z[:, :, :512, :512] - zc[:, :, :512, :512]).abs().max()
+        assert float(d) < 1e-4 * float(zc.abs().max())           # same arithmetic, different tile grid -> fp32 noise only
+        zs = net(xs)
+        zcs = cw.transfer(z, zs)
+        a, b = zcs[0].reshape(32, -1).double(), zs[0].reshape(32, -1).double()
+        assert float((a.mean(-1) - b.mean(-1)).abs().max()) < 1e-5
+        assert float((_cov(a) - _cov(b)).abs().max() / _cov(b).abs().max()) < 1e-4
+        del zcs, a
+        out = net.inverse_u8(cw.transfer(z, zs))
+        assert out.shape == (1, 4096, 4096, 3) and out.dtype == torch.uint8
+
+
+def test_full_size_config5_1080p_masked():
+    """config 5's frame: 1920x1080, 5-label masks (+ a 6-pixel speck that must stay untouched).  Property: inside every
+    valid label the transferred code has the moments of the style code inside the same label; the speck keeps the
+    content code."""
+    from models.cWCT import cWCT
+    net, sd, sp = make_net("photo")
+    cw = cWCT()
+    H, W = 1080, 1920
+    x = synthetic_frames(1, H, W, seed=21).cuda()
+    xs = synthetic_frames(1, H, W, seed=22).cuda()
+    cm, sm = synthetic_mask(H, W, 5, seed=3)[None], synthetic_mask(H, W, 5, seed=4, speck=False)[None]
+    with torch.no_grad():
+        zc, zs = net(x), net(xs)
+        zc0 = zc.clone()
+        zcs = cw.transfer(zc, zs, cm, sm)
+    cmt, smt = T(cm[0]).cuda().reshape(-1), T(sm[0]).cuda().reshape(-1)
+    a_all, b_all, c_all = zcs[0].reshape(32, -1), zs[0].reshape(32, -1), zc0[0].reshape(32, -1)
+    for label in range(5):
+        a, b = a_all[:, cmt == label].double(), b_all[:, smt == label].double()
+        assert a.shape[1] > 10 and b.shape[1] > 10
+        assert float((a.mean(-1) - b.mean(-1)).abs().max()) < 2e-5 * max(1.0, float(b.mean(-1).abs().max()))
+        assert float((_cov(a) - _cov(b)).abs().max() / _cov(b).abs().max()) < 2e-4, label
+    speck = cmt == 5
+    assert int(speck.sum()) == 6 and torch.equal(a_all[:, speck], c_all[:, speck])
