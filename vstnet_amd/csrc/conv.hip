@@ -153,7 +153,10 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, float* out_img, in
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc, 0, 0, 0);        \
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc, 0, 0, 0)
 
-// ---- generic kernel: synchronous staging per input-channel chunk (all shapes) ----------------------
+#ifndef VST_EARLY_OLD
+#define VST_EARLY_OLD 1
+#endif
+// ---- generic kernel: one tile per workgroup, staging per input-channel chunk (all shapes) --------------
 template <int CIN, int COUT, int STRIDE, bool IN_STATE, bool OUT_STATE>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     using C = ConvCfg<CIN, COUT, STRIDE>;
@@ -184,62 +187,84 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     // per-lane slot of tile row (wave*MR), pixel lrow, tap (0,0)
     const int slot_base = (wave * C::MR * STRIDE) * C::IW + lrow * STRIDE;
 
+    // Staging is split into "fetch" (global -> registers) and "land" (bf16 split, registers -> LDS) so that the
+    // latencies overlap: weights and activations of a chunk are fetched together, the next chunk is fetched before this
+    // chunk's MFMAs, and the read-modify-write state values are fetched before the last chunk's MFMAs wherever they
+    // fit in registers that are dead until the epilogue (s_memtime stamps of the synchronous form showed the weight
+    // fetch, the second chunk's fetch and the old-state fetch as 2-2.5 us waits each in a 13 us workgroup).
+    constexpr int A_ITEMS_T = CIN == 4 ? C::IH * C::IW : C::IH * C::IW * C::CIG;
+    constexpr int AIT = (A_ITEMS_T + 255) / 256, NV = CIN == 4 ? 1 : 2;
+    constexpr int W_ITEMS_T = C::KS * 4 * C::NT, WIT = (W_ITEMS_T + 255) / 256;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // native vectors: these arrays must stay in VGPRs
+    f32x4 areg[AIT][NV];
+    u32x4 wreg[WIT][2];
+#define F4(v_) make_float4((v_)[0], (v_)[1], (v_)[2], (v_)[3])
+#define GEN_FETCH(chunk_)                                                                           \
+    _Pragma("unroll") for (int it = 0; it < WIT; ++it) {                                           \
+        int idx = it * 256 + tid;                                                                  \
+        idx = idx < W_ITEMS_T ? idx : W_ITEMS_T - 1;                                               \
+        const int co = idx % C::NT, r = idx / C::NT;                                               \
+        const size_t src = ((size_t)((chunk_) * C::KS * 4 + r) * C::COUTP + co0 + co) * 16;        \
+        wreg[it][0] = *(const u32x4*)(w_hi + src);                                                 \
+        wreg[it][1] = *(const u32x4*)(w_lo + src);                                                 \
+    }                                                                                              \
+    _Pragma("unroll") for (int it = 0; it < AIT; ++it) {                                           \
+        int idx = it * 256 + tid;                                                                  \
+        idx = idx < A_ITEMS_T ? idx : A_ITEMS_T - 1;                                               \
+        const int cig = CIN == 4 ? 0 : idx % C::CIG, slot = CIN == 4 ? idx : idx / C::CIG;         \
+        const int iy = slot / C::IW, ix = slot - iy * C::IW;                                       \
+        const int gy = reflect_clamp(ty0 * STRIDE - 1 + iy, a.Hin);                                \
+        const int gx = reflect_clamp(tx0 * STRIDE - 1 + ix, a.Win);                                \
+        const size_t off = IN_STATE ? zc_offset(vst_level_of_channels(CIN), gy, gx, a.Wq)          \
+                                    : ((size_t)gy * a.Win + gx) * CIN;                             \
+        const float* p = in_img + off + (chunk_) * C::CC + cig * 8;                                \
+        areg[it][0] = *(const f32x4*)p;                                                            \
+        if (NV == 2) areg[it][NV - 1] = *(const f32x4*)(p + 4);                                    \
+    }
+    // threads past the end repeat the last item (same value to the same address): no predicates, so the compiler keeps
+    // every fetch where it was issued
+#define GEN_LAND()                                                                                 \
+    _Pragma("unroll") for (int it = 0; it < AIT; ++it) {                                           \
+        int idx = it * 256 + tid;                                                                  \
+        idx = idx < A_ITEMS_T ? idx : A_ITEMS_T - 1;                                               \
+        if (CIN == 4) {                                                                            \
+            uint2 h, l;                                                                            \
+            split4(F4(areg[it][0]), h, l);                                                         \
+            *(uint2*)(a_hi + idx * 8) = h;                                                         \
+            *(uint2*)(a_lo + idx * 8) = l;                                                         \
+        } else {                                                                                   \
+            const int cig = idx % C::CIG, slot = idx / C::CIG;                                     \
+            uint4 h, l;                                                                            \
+            split8(F4(areg[it][0]), F4(areg[it][NV - 1]), h, l);                                   \
+            *(uint4*)(a_hi + (cig * C::NSLOT + slot) * 16) = h;                                    \
+            *(uint4*)(a_lo + (cig * C::NSLOT + slot) * 16) = l;                                    \
+        }                                                                                          \
+    }                                                                                              \
+    _Pragma("unroll") for (int it = 0; it < WIT; ++it) {                                           \
+        int idx = it * 256 + tid;                                                                  \
+        idx = idx < W_ITEMS_T ? idx : W_ITEMS_T - 1;                                               \
+        *(u32x4*)(b_hi + idx * 16) = wreg[it][0];                                                  \
+        *(u32x4*)(b_lo + idx * 16) = wreg[it][1];                                                  \
+    }
+
+    float* const out_img = a.out + (size_t)b * a.out_img_stride;
+    float4 bias[C::NB], old[C::MR][C::NB];
+    const bool interior = COUT % 16 == 0 && ty0 + C::TH <= a.Hout && tx0 + C::TW <= a.Wout;   // no predicates needed
+    // fetch the old state before the MFMAs only where its registers are free anyway (big register tiles: the 16-value
+    // tiles of the 4->16 conv lose more to occupancy than they gain)
+    constexpr bool EARLY_OLD = OUT_STATE && VST_EARLY_OLD && C::MR * C::NB >= 16;
+    auto fetch_old = [&]() __attribute__((always_inline)) {
+        if (interior) load_old<COUT, C::MR, C::NB, true>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, old);
+        else load_old<COUT, C::MR, C::NB>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, old);
+    };
+
+    GEN_FETCH(0);
+    GEN_LAND();
+#pragma unroll
     for (int chunk = 0; chunk < C::NCHUNK; ++chunk) {
-        if (chunk > 0) __syncthreads();
-        // ---- stage activations: fp32 -> bf16 hi/lo image ------------------------------------------
-        if (CIN == 4) {
-            constexpr int ITEMS = C::IH * C::IW;
-#pragma unroll
-            for (int it = 0; it < (ITEMS + 255) / 256; ++it) {
-                const int slot = it * 256 + tid;
-                if (slot < ITEMS) {
-                    const int iy = slot / C::IW, ix = slot - iy * C::IW;
-                    const int gy = reflect_clamp(ty0 * STRIDE - 1 + iy, a.Hin);
-                    const int gx = reflect_clamp(tx0 * STRIDE - 1 + ix, a.Win);
-                    const float4 v = *(const float4*)(in_img + ((size_t)gy * a.Win + gx) * 4);
-                    uint2 h, l;
-                    split4(v, h, l);
-                    *(uint2*)(a_hi + slot * 8) = h;
-                    *(uint2*)(a_lo + slot * 8) = l;
-                }
-            }
-        } else {
-            constexpr int ITEMS = C::IH * C::IW * C::CIG;
-#pragma unroll
-            for (int it = 0; it < (ITEMS + 255) / 256; ++it) {
-                const int idx = it * 256 + tid;
-                if (idx < ITEMS) {
-                    const int cig = idx % C::CIG, slot = idx / C::CIG;
-                    const int iy = slot / C::IW, ix = slot - iy * C::IW;
-                    const int gy = reflect_clamp(ty0 * STRIDE - 1 + iy, a.Hin);
-                    const int gx = reflect_clamp(tx0 * STRIDE - 1 + ix, a.Win);
-                    const size_t off = IN_STATE ? zc_offset(vst_level_of_channels(CIN), gy, gx, a.Wq)
-                                                : ((size_t)gy * a.Win + gx) * CIN;
-                    const float* p = in_img + off + chunk * C::CC + cig * 8;
-                    const float4 v0 = *(const float4*)p;
-                    const float4 v1 = *(const float4*)(p + 4);
-                    uint4 h, l;
-                    split8(v0, v1, h, l);
-                    *(uint4*)(a_hi + (cig * C::NSLOT + slot) * 16) = h;
-                    *(uint4*)(a_lo + (cig * C::NSLOT + slot) * 16) = l;
-                }
-            }
-        }
-        // ---- stage weights: packed fragments -> LDS ------------------------------------------------
-        {
-            constexpr int ITEMS = C::KS * 4 * C::NT;
-#pragma unroll
-            for (int it = 0; it < (ITEMS + 255) / 256; ++it) {
-                const int idx = it * 256 + tid;
-                if (idx < ITEMS) {
-                    const int co = idx % C::NT, r = idx / C::NT;
-                    const size_t src = ((size_t)(chunk * C::KS * 4 + r) * C::COUTP + co0 + co) * 16;
-                    *(uint4*)(b_hi + idx * 16) = *(const uint4*)(w_hi + src);
-                    *(uint4*)(b_lo + idx * 16) = *(const uint4*)(w_lo + src);
-                }
-            }
-        }
         __syncthreads();
+        if (chunk + 1 < C::NCHUNK) { GEN_FETCH(chunk + 1); }
+        if (EARLY_OLD && chunk == C::NCHUNK - 1) fetch_old();
 
         // ---- MFMA over the chunk's k steps ---------------------------------------------------------
 #pragma unroll
@@ -283,18 +308,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                 for (int n = 0; n < C::NB; ++n) { MFMA3(acc[m][n], wh[n], wl[n], xh, xl); }
             }
         }
+        if (chunk + 1 < C::NCHUNK) {
+            __syncthreads();
+            GEN_LAND();
+        }
     }
+#undef GEN_FETCH
+#undef GEN_LAND
+#undef F4
 
-    float* const out_img = a.out + (size_t)b * a.out_img_stride;
-    float4 bias[C::NB], old[C::MR][C::NB];
     load_bias<COUT, C::NB>(a, co0 + 4 * kg, bias);
-    if (COUT % 16 == 0 && ty0 + C::TH <= a.Hout && tx0 + C::TW <= a.Wout) {      // interior tile: no predicates
-        if (OUT_STATE) load_old<COUT, C::MR, C::NB, true>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, old);
-        store_tile<COUT, OUT_STATE, C::MR, C::NB, true>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, acc, bias, old);
-    } else {
-        if (OUT_STATE) load_old<COUT, C::MR, C::NB>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, old);
-        store_tile<COUT, OUT_STATE, C::MR, C::NB>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, acc, bias, old);
-    }
+    if (OUT_STATE && !EARLY_OLD) fetch_old();
+    if (interior) store_tile<COUT, OUT_STATE, C::MR, C::NB, true>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, acc, bias, old);
+    else store_tile<COUT, OUT_STATE, C::MR, C::NB>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, acc, bias, old);
 }
 
 // ---- pipelined kernel for the MFMA-bound shapes: CIN in {64,256}, COUT in {64,256}, stride 1 --------
