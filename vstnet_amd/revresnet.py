@@ -131,6 +131,8 @@ class RevResNet(nn.Module):
                 cw = net.blocks[k // 3].conv[k % 3]
                 cw.packed = blob.data_ptr() + int(offsets[k])
                 cw.bias = b.data_ptr()
+            # one-off: the packed blob may be used from any stream afterwards (frames in flight on several streams)
+            torch.cuda.current_stream(device).synchronize()
         self._packed = (device, blob, biases, net)
         return net
 
