@@ -31,6 +31,8 @@ struct ConvArgs {
     size_t out_img_stride;
     float sign;                  // OUT_STATE: out += sign * (conv + bias)
     int tiles_x, tiles_y, tiles_total;   // 1-D grid of round_up(tiles_total, 8) workgroups, see xcd_tile()
+    const unsigned char* packed1;        // conv_pair_kernel: conv.4's packed weights and bias (in = h1)
+    const float* bias1;
 };
 
 // Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2.  Give XCD k the contiguous
@@ -323,6 +325,272 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     else store_tile<COUT, OUT_STATE, C::MR, C::NB>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, acc, bias, old);
 }
 
+// ---- conv.4 + conv.7 of one stage-1 / stage-2 coupling block in one launch -----------------------------------------
+// h2 = ReLU(conv.4(h1)) never goes to HBM: the workgroup computes it for its 16x16 tile plus a one-pixel ring
+// (18x18 positions, from a 20x20 region of h1) into the LDS image that conv.7's MFMAs read, then does
+// dst += sign * (conv.7(h2) + bias).  ReflectionPad of h2 (RevResNet.py:85): an in-image pixel one step inside the
+// border also writes the mirrored ring slot.  LDS: [h2 image][ union { h1 region + conv.4 weights ; conv.7 weights } ].
+template <int CIN>
+__device__ __forceinline__ void read_x_small(const unsigned char* img_hi, const unsigned char* img_lo, int nslot,
+                                             int slot00, int iw, int ks, int kg, bf16x8& xh, bf16x8& xl) {
+    if (CIN == 16) {
+        int tap = 2 * ks + (kg >> 1);
+        tap = tap > 8 ? 8 : tap;
+        const int slot = slot00 + (tap / 3) * iw + tap % 3;
+        const int aoff = ((kg & 1) * nslot + slot) * 16;
+        xh = __builtin_bit_cast(bf16x8, *(const uint4*)(img_hi + aoff));
+        xl = __builtin_bit_cast(bf16x8, *(const uint4*)(img_lo + aoff));
+    } else {
+        int t0 = 8 * ks + 2 * kg;
+        t0 = t0 > 8 ? 8 : t0;
+        const int t1 = t0 + 1 > 8 ? 8 : t0 + 1;
+        const int s0 = slot00 + (t0 / 3) * iw + t0 % 3, s1 = slot00 + (t1 / 3) * iw + t1 % 3;
+        const uint2 h0 = *(const uint2*)(img_hi + s0 * 8), h1 = *(const uint2*)(img_hi + s1 * 8);
+        const uint2 l0 = *(const uint2*)(img_lo + s0 * 8), l1 = *(const uint2*)(img_lo + s1 * 8);
+        xh = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+        xl = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+    }
+}
+
+template <int MID, int CH>
+struct PairCfg {
+    using C7 = ConvCfg<MID, CH, 1>;
+    static constexpr int R1 = 20, N1SLOT = 400, RW = 18, NPX = 324, NBLK = (NPX + 15) / 16;   // h1 region, h2 ring region
+    static constexpr int H1_PLANE = MID == 4 ? N1SLOT * 8 : C7::CIG * N1SLOT * 16;
+    static constexpr int W4_PLANE = C7::KS * 4 * 16 * 16;
+    // MID == 16: conv.7's 40 KB of weights take over the h1 region + conv.4 weights once conv.4 is done (62 KB, two
+    // workgroups per CU); MID == 4: everything is small, conv.7's weights get their own region (one barrier fewer)
+    static constexpr bool ALIAS = MID == 16;
+    static constexpr int H1W4 = 2 * H1_PLANE + 2 * W4_PLANE;
+    static constexpr int U_BYTES = ALIAS ? (H1W4 > 2 * C7::B_PLANE ? H1W4 : 2 * C7::B_PLANE) : H1W4 + 2 * C7::B_PLANE;
+    static constexpr int LDS_BYTES = 2 * C7::A_PLANE + U_BYTES;
+};
+
+template <int MID, int CH>
+__global__ __launch_bounds__(256) void conv_pair_kernel(const ConvArgs a) {
+    using P = PairCfg<MID, CH>;
+    using C = typename P::C7;
+    static_assert(C::NCHUNK == 1 && C::NCOT == 1, "single-chunk shapes");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const a_hi = smem;                        // h2 image (conv.7's activation image)
+    unsigned char* const a_lo = smem + C::A_PLANE;
+    unsigned char* const u0 = smem + 2 * C::A_PLANE;
+    unsigned char* const b_hi = P::ALIAS ? u0 : u0 + P::H1W4;   // conv.7 weights (aliased: valid after conv.4 is done)
+    unsigned char* const b_lo = b_hi + C::B_PLANE;
+    unsigned char* const h1_hi = u0;                         // h1 region + conv.4 weights (before)
+    unsigned char* const h1_lo = u0 + P::H1_PLANE;
+    unsigned char* const w4s_hi = u0 + 2 * P::H1_PLANE;
+    unsigned char* const w4s_lo = w4s_hi + P::W4_PLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, kg = lane >> 4;
+    int bx, by, b;
+    if (!xcd_tile(a, bx, by, b)) return;
+    const int tx0 = bx * C::TW, ty0 = by * C::TH;
+    const int H = a.Hout, W = a.Wout;                        // h1, h2 and the output view share one resolution
+    const float* const in_img = a.in + (size_t)b * a.in_img_stride;
+    float* const out_img = a.out + (size_t)b * a.out_img_stride;
+    const PackedConvLayout PL7 = packed_conv_layout(CH, MID), PL4 = packed_conv_layout(MID, MID);
+    const unsigned char* const w7_hi = a.packed + PL7.f32_bytes;
+    const unsigned char* const w7_lo = w7_hi + PL7.frag_bytes;
+    const unsigned char* const w4_hi = a.packed1 + PL4.f32_bytes;
+    const unsigned char* const w4_lo = w4_hi + PL4.frag_bytes;
+
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    constexpr int H1_ITEMS = MID == 4 ? P::N1SLOT : P::N1SLOT * C::CIG, H1IT = (H1_ITEMS + 255) / 256, NV = MID == 4 ? 1 : 2;
+    constexpr int W4_ITEMS = C::KS * 4 * 16, W4IT = (W4_ITEMS + 255) / 256;
+    constexpr int W7_ITEMS = C::KS * 4 * C::NT, W7IT = (W7_ITEMS + 255) / 256;
+    f32x4 hreg[H1IT][NV];
+    u32x4 w4reg[W4IT][2], w7reg[W7IT][2];
+    // ---- fetch everything this workgroup reads, back to back ---------------------------------------------------------
+#pragma unroll
+    for (int it = 0; it < W4IT; ++it) {
+        int idx = it * 256 + tid;
+        idx = idx < W4_ITEMS ? idx : W4_ITEMS - 1;
+        w4reg[it][0] = *(const u32x4*)(w4_hi + (size_t)idx * 16);      // coutp == 16: fragment order is already [r][co]
+        w4reg[it][1] = *(const u32x4*)(w4_lo + (size_t)idx * 16);
+    }
+#pragma unroll
+    for (int it = 0; it < H1IT; ++it) {
+        int idx = it * 256 + tid;
+        idx = idx < H1_ITEMS ? idx : H1_ITEMS - 1;
+        const int cig = MID == 4 ? 0 : idx % C::CIG, slot = MID == 4 ? idx : idx / C::CIG;
+        const int iy = slot / P::R1, ix = slot - iy * P::R1;
+        const int gy = reflect_clamp(ty0 - 2 + iy, H), gx = reflect_clamp(tx0 - 2 + ix, W);
+        const float* p = in_img + ((size_t)gy * W + gx) * MID + cig * 8;
+        hreg[it][0] = *(const f32x4*)p;
+        if (NV == 2) hreg[it][NV - 1] = *(const f32x4*)(p + 4);
+    }
+#pragma unroll
+    for (int it = 0; it < W7IT; ++it) {
+        int idx = it * 256 + tid;
+        idx = idx < W7_ITEMS ? idx : W7_ITEMS - 1;
+        const int co = idx % C::NT, r = idx / C::NT;
+        const size_t src = ((size_t)r * C::COUTP + co) * 16;
+        w7reg[it][0] = *(const u32x4*)(w7_hi + src);
+        w7reg[it][1] = *(const u32x4*)(w7_lo + src);
+    }
+    float4 bias[C::NB], old[C::MR][C::NB];
+    const bool interior = ty0 + C::TH <= H && tx0 + C::TW <= W;
+    constexpr bool EARLY_OLD = C::MR * C::NB >= 16;          // as in the generic kernel: not where it costs occupancy
+#define PAIR_FETCH_OLD()                                                                                         \
+    if (interior) load_old<CH, C::MR, C::NB, true>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, 4 * kg, old);   \
+    else load_old<CH, C::MR, C::NB>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, 4 * kg, old);
+    if (EARLY_OLD) { PAIR_FETCH_OLD(); }
+
+    // ---- land h1 (bf16 split) and conv.4's weights --------------------------------------------------------------------
+#define F4(v_) make_float4((v_)[0], (v_)[1], (v_)[2], (v_)[3])
+#pragma unroll
+    for (int it = 0; it < H1IT; ++it) {
+        int idx = it * 256 + tid;
+        idx = idx < H1_ITEMS ? idx : H1_ITEMS - 1;
+        if (MID == 4) {
+            uint2 h, l;
+            split4(F4(hreg[it][0]), h, l);
+            *(uint2*)(h1_hi + idx * 8) = h;
+            *(uint2*)(h1_lo + idx * 8) = l;
+        } else {
+            const int cig = idx % C::CIG, slot = idx / C::CIG;
+            uint4 h, l;
+            split8(F4(hreg[it][0]), F4(hreg[it][NV - 1]), h, l);
+            *(uint4*)(h1_hi + (cig * P::N1SLOT + slot) * 16) = h;
+            *(uint4*)(h1_lo + (cig * P::N1SLOT + slot) * 16) = l;
+        }
+    }
+#undef F4
+#pragma unroll
+    for (int it = 0; it < W4IT; ++it) {
+        int idx = it * 256 + tid;
+        idx = idx < W4_ITEMS ? idx : W4_ITEMS - 1;
+        *(u32x4*)(w4s_hi + idx * 16) = w4reg[it][0];
+        *(u32x4*)(w4s_lo + idx * 16) = w4reg[it][1];
+    }
+#define LAND_W7()                                                                                  \
+    _Pragma("unroll") for (int it = 0; it < W7IT; ++it) {                                          \
+        int idx = it * 256 + tid;                                                                  \
+        idx = idx < W7_ITEMS ? idx : W7_ITEMS - 1;                                                 \
+        *(u32x4*)(b_hi + idx * 16) = w7reg[it][0];                                                 \
+        *(u32x4*)(b_lo + idx * 16) = w7reg[it][1];                                                 \
+    }
+    if (!P::ALIAS) { LAND_W7(); }
+    __syncthreads();
+
+    // ---- conv.4 on the 18x18 ring region: 16-pixel blocks of the linearised region, one 16-channel block ---------------
+    {
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (4 * kg < MID) b4 = *(const float4*)(a.bias1 + 4 * kg);
+        constexpr bool HOIST = MID == 4;                        // conv.4's fragments are the same for every pixel block;
+        bf16x8 w4h[HOIST ? C::KS : 1], w4l[HOIST ? C::KS : 1];   // keep them in registers where there is room
+        if (HOIST) {
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) {
+                const int boff = ((ks * 4 + kg) * 16 + lrow) * 16;
+                w4h[HOIST ? ks : 0] = __builtin_bit_cast(bf16x8, *(const uint4*)(w4s_hi + boff));
+                w4l[HOIST ? ks : 0] = __builtin_bit_cast(bf16x8, *(const uint4*)(w4s_lo + boff));
+            }
+        }
+        // two pixel blocks per iteration (independent MFMA chains); the second may be past the end (clamped, not written)
+        for (int blk0 = wave; blk0 < P::NBLK; blk0 += 8) {
+            f32x4 acc4[2];
+            int ryv[2], rxv[2];
+            bool okv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                int p = (blk0 + 4 * u) * 16 + lrow;
+                okv[u] = p < P::NPX;
+                p = okv[u] ? p : P::NPX - 1;
+                ryv[u] = p / P::RW; rxv[u] = p - ryv[u] * P::RW;
+                acc4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) {
+                bf16x8 wh, wl;
+                if (HOIST) {
+                    wh = w4h[HOIST ? ks : 0]; wl = w4l[HOIST ? ks : 0];
+                } else {
+                    const int boff = ((ks * 4 + kg) * 16 + lrow) * 16;
+                    wh = __builtin_bit_cast(bf16x8, *(const uint4*)(w4s_hi + boff));
+                    wl = __builtin_bit_cast(bf16x8, *(const uint4*)(w4s_lo + boff));
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    bf16x8 xh, xl;
+                    read_x_small<MID>(h1_hi, h1_lo, P::N1SLOT, ryv[u] * P::R1 + rxv[u], P::R1, ks, kg, xh, xl);
+                    MFMA3(acc4[u], wh, wl, xh, xl);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                // lane (lrow, kg) holds channels 4kg..4kg+3 of region pixel (ry, rx)
+                const int ry = ryv[u], rx = rxv[u];
+                const int gy = ty0 - 1 + ry, gx = tx0 - 1 + rx;
+                if (okv[u] && 4 * kg < MID && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    float4 v = make_float4(acc4[u][0] + b4.x, acc4[u][1] + b4.y, acc4[u][2] + b4.z, acc4[u][3] + b4.w);
+                    v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+                    v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                    uint2 h, l;
+                    split4(v, h, l);
+                    // own slot + the mirrored ring slots (ReflectionPad2d(1) of h2): row -1 <- row 1, row H <- row H-2, same in x
+                    const int my = gy == 1 ? -2 : (gy == H - 2 ? 2 : 0), mx = gx == 1 ? -2 : (gx == W - 2 ? 2 : 0);
+#pragma unroll
+                    for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+                        for (int ix = 0; ix < 2; ++ix) {
+                            if ((iy && !my) || (ix && !mx)) continue;
+                            const int sy = ry + (iy ? my : 0), sx = rx + (ix ? mx : 0);
+                            if (sy < 0 || sy >= P::RW || sx < 0 || sx >= P::RW) continue;
+                            const int slot = sy * C::IW + sx;
+                            if (MID == 4) {
+                                *(uint2*)(a_hi + slot * 8) = h;
+                                *(uint2*)(a_lo + slot * 8) = l;
+                            } else {
+                                const int off = ((kg >> 1) * C::NSLOT + slot) * 16 + (kg & 1) * 8;
+                                *(uint2*)(a_hi + off) = h;
+                                *(uint2*)(a_lo + off) = l;
+                            }
+                        }
+                }
+            }
+        }
+    }
+    __syncthreads();                                         // h2 image complete; h1 region and conv.4 weights are dead
+    if (P::ALIAS) {
+        LAND_W7();
+        __syncthreads();
+    }
+#undef LAND_W7
+
+    // ---- conv.7 from the LDS image, state read-modify-write -------------------------------------------------------------
+    f32x4 acc[C::MR][C::NB];
+#pragma unroll
+    for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+        for (int n = 0; n < C::NB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int slot_base = (wave * C::MR) * C::IW + lrow;
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+        bf16x8 wh[C::NB], wl[C::NB];
+#pragma unroll
+        for (int n = 0; n < C::NB; ++n) {
+            const int boff = ((ks * 4 + kg) * C::NT + n * 16 + lrow) * 16;
+            wh[n] = __builtin_bit_cast(bf16x8, *(const uint4*)(b_hi + boff));
+            wl[n] = __builtin_bit_cast(bf16x8, *(const uint4*)(b_lo + boff));
+        }
+#pragma unroll
+        for (int m = 0; m < C::MR; ++m) {
+            bf16x8 xh, xl;
+            read_x_small<MID>(a_hi, a_lo, C::NSLOT, slot_base + m * C::IW, C::IW, ks, kg, xh, xl);
+#pragma unroll
+            for (int n = 0; n < C::NB; ++n) { MFMA3(acc[m][n], wh[n], wl[n], xh, xl); }
+        }
+    }
+    load_bias<CH, C::NB>(a, 4 * kg, bias);
+    if (!EARLY_OLD) { PAIR_FETCH_OLD(); }
+#undef PAIR_FETCH_OLD
+    if (interior) store_tile<CH, true, C::MR, C::NB, true>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, 4 * kg, acc, bias, old);
+    else store_tile<CH, true, C::MR, C::NB>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, 4 * kg, acc, bias, old);
+}
+
 // ---- pipelined kernel for the MFMA-bound shapes: CIN in {64,256}, COUT in {64,256}, stride 1 --------
 // A stage = (32-channel chunk, tap row dy) = 3 k-steps = 144 MFMAs per wave.  Two activation buffers
 // and two weight buffers in LDS; while stage s computes, the wave prefetches stage s+1's weights and a
@@ -606,6 +874,25 @@ static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) 
     return VST_OK;
 }
 
+#ifndef VST_PAIR
+#define VST_PAIR 1
+#endif
+template <int MID, int CH>
+static int launch_pair(const ConvArgs& a, int B, hipStream_t st) {
+    using P = PairCfg<MID, CH>;
+    const bool timed = g_prof_kernel == VST_KERNEL_ID(MID, CH, 1) && g_prof_count < g_prof_cap;
+    if (timed) (void)hipEventRecord(g_prof_ev[2 * g_prof_count], st);
+    auto kern = conv_pair_kernel<MID, CH>;
+    static unsigned attr_done = 0;
+    if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)(P::LDS_BYTES), &attr_done)) return rc_;
+    ConvArgs t = a;
+    t.tiles_x = (a.Wout + 15) / 16; t.tiles_y = (a.Hout + 15) / 16; t.tiles_total = t.tiles_x * t.tiles_y * B;
+    kern<<<dim3((t.tiles_total + 7) / 8 * 8), 256, P::LDS_BYTES, st>>>(t);
+    if (timed) { (void)hipEventRecord(g_prof_ev[2 * g_prof_count + 1], st); ++g_prof_count; }
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
 // one coupling block: dst (+/-)= F(src), three launches (h1, h2 are fp32 channels-last intermediates)
 template <int CH, int STRIDE>
 static int run_block(const vst_block_weights* w, int direction, int precision, float* dst, const float* src,
@@ -626,6 +913,15 @@ static int run_block(const vst_block_weights* w, int direction, int precision, f
     a.in_img_stride = state_img; a.out_img_stride = mid_img; a.sign = 0.f;
     int rc = launch_conv<IN_CH, MID, STRIDE, true, false>(a, B, precision, st);
     if (rc) return rc;
+    if constexpr (CH <= 64 && VST_PAIR) {
+        if (precision == VST_PREC_BF16X3) {       // conv.4 + conv.7 in one launch, h2 stays in LDS
+            a.in = h1; a.out = dst; a.Hin = Ho; a.Win = Wo; a.in_img_stride = mid_img; a.out_img_stride = state_img;
+            a.packed = (const unsigned char*)w->conv[2].packed; a.bias = w->conv[2].bias;
+            a.packed1 = (const unsigned char*)w->conv[1].packed; a.bias1 = w->conv[1].bias;
+            a.sign = direction > 0 ? 1.f : -1.f;
+            return launch_pair<MID, CH>(a, B, st);
+        }
+    }
     // conv.4: h1 -> h2 (ReLU)
     a.in = h1; a.out = h2; a.packed = (const unsigned char*)w->conv[1].packed; a.bias = w->conv[1].bias;
     a.Hin = Ho; a.Win = Wo; a.in_img_stride = mid_img;
