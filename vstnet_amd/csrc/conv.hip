@@ -479,6 +479,7 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const ConvArgs a) {
     {
         float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (4 * kg < MID) b4 = *(const float4*)(a.bias1 + 4 * kg);
+        const bool ring_inside = ty0 >= 1 && tx0 >= 1 && ty0 + 17 <= H && tx0 + 17 <= W;
         constexpr bool HOIST = MID == 4;                        // conv.4's fragments are the same for every pixel block;
         bf16x8 w4h[HOIST ? C::KS : 1], w4l[HOIST ? C::KS : 1];   // keep them in registers where there is room
         if (HOIST) {
@@ -523,33 +524,38 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const ConvArgs a) {
             for (int u = 0; u < 2; ++u) {
                 // lane (lrow, kg) holds channels 4kg..4kg+3 of region pixel (ry, rx)
                 const int ry = ryv[u], rx = rxv[u];
-                const int gy = ty0 - 1 + ry, gx = tx0 - 1 + rx;
-                if (okv[u] && 4 * kg < MID && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                    float4 v = make_float4(acc4[u][0] + b4.x, acc4[u][1] + b4.y, acc4[u][2] + b4.z, acc4[u][3] + b4.w);
-                    v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
-                    v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
-                    uint2 h, l;
-                    split4(v, h, l);
-                    // own slot + the mirrored ring slots (ReflectionPad2d(1) of h2): row -1 <- row 1, row H <- row H-2, same in x
-                    const int my = gy == 1 ? -2 : (gy == H - 2 ? 2 : 0), mx = gx == 1 ? -2 : (gx == W - 2 ? 2 : 0);
-#pragma unroll
-                    for (int iy = 0; iy < 2; ++iy)
-#pragma unroll
-                        for (int ix = 0; ix < 2; ++ix) {
-                            if ((iy && !my) || (ix && !mx)) continue;
-                            const int sy = ry + (iy ? my : 0), sx = rx + (ix ? mx : 0);
-                            if (sy < 0 || sy >= P::RW || sx < 0 || sx >= P::RW) continue;
-                            const int slot = sy * C::IW + sx;
-                            if (MID == 4) {
-                                *(uint2*)(a_hi + slot * 8) = h;
-                                *(uint2*)(a_lo + slot * 8) = l;
-                            } else {
-                                const int off = ((kg >> 1) * C::NSLOT + slot) * 16 + (kg & 1) * 8;
-                                *(uint2*)(a_hi + off) = h;
-                                *(uint2*)(a_lo + off) = l;
-                            }
-                        }
+                float4 v = make_float4(acc4[u][0] + b4.x, acc4[u][1] + b4.y, acc4[u][2] + b4.z, acc4[u][3] + b4.w);
+                v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+                v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                uint2 h, l;
+                split4(v, h, l);
+#define PAIR_PUT(slot_)                                                                            \
+                if (MID == 4) {                                                                    \
+                    *(uint2*)(a_hi + (slot_) * 8) = h;                                             \
+                    *(uint2*)(a_lo + (slot_) * 8) = l;                                             \
+                } else {                                                                           \
+                    const int off_ = ((kg >> 1) * C::NSLOT + (slot_)) * 16 + (kg & 1) * 8;         \
+                    *(uint2*)(a_hi + off_) = h;                                                    \
+                    *(uint2*)(a_lo + off_) = l;                                                    \
                 }
+                if (ring_inside) {                           // uniform: the whole 18x18 ring region lies inside the image
+                    if (okv[u] && 4 * kg < MID) { PAIR_PUT(ry * C::IW + rx); }
+                } else {
+                    const int gy = ty0 - 1 + ry, gx = tx0 - 1 + rx;
+                    if (okv[u] && 4 * kg < MID && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                        // own slot + the mirrored ring slots (ReflectionPad2d(1) of h2): row -1 <- row 1, row H <- row H-2,
+                        // same in x; where no mirror applies the same slot is written again
+                        const int my = gy == 1 ? -2 : (gy == H - 2 ? 2 : 0), mx = gx == 1 ? -2 : (gx == W - 2 ? 2 : 0);
+                        int sy = ry + my, sx = rx + mx;
+                        sy = (sy < 0 || sy >= P::RW) ? ry : sy;
+                        sx = (sx < 0 || sx >= P::RW) ? rx : sx;
+                        PAIR_PUT(ry * C::IW + rx);
+                        PAIR_PUT(sy * C::IW + rx);
+                        PAIR_PUT(ry * C::IW + sx);
+                        PAIR_PUT(sy * C::IW + sx);
+                    }
+                }
+#undef PAIR_PUT
             }
         }
     }
