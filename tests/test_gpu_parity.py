@@ -646,3 +646,21 @@ def test_full_size_config5_1080p_masked():
         assert float((_cov(a) - _cov(b)).abs().max() / _cov(b).abs().max()) < 2e-4, label
     speck = cmt == 5
     assert int(speck.sum()) == 6 and torch.equal(a_all[:, speck], c_all[:, speck])
+
+
+def test_network_vs_oracle_seeded_shapes():
+    """a seeded sweep of odd frame shapes (tile edges in every position, batches, both modes) against the oracle"""
+    rng = np.random.default_rng(2024)
+    nets = {m: make_net(m) for m in ("photo", "art")}
+    for case in range(10):
+        mode = "photo" if case % 3 else "art"
+        net, sd, sp = nets[mode]
+        B = int(rng.integers(1, 4))
+        H, W = (int(4 * rng.integers(2, 41)), int(4 * rng.integers(2, 41)))
+        x = synthetic_frames(B, 8 * ((H + 7) // 8), 8 * ((W + 7) // 8), seed=100 + case)[:, :, :H, :W].contiguous()
+        with torch.no_grad():
+            zr = cpu_ref.revnet_forward(x, sd, sp)
+            z = net(x.cuda())
+            assert_close(z, zr, TIGHT, f"{mode} {B}x{H}x{W} forward")
+            zp = zr + 0.02 * torch.randn(zr.shape, generator=torch.Generator().manual_seed(case))
+            assert_close(net(zp.cuda(), forward=False), cpu_ref.revnet_inverse(zp, sd, sp), TIGHT, f"{mode} {B}x{H}x{W} inverse")
