@@ -106,3 +106,43 @@ def test_compute_label_info_matches_oracle(golden):
     l2, ok2 = cpu_ref.compute_label_info(g["cmask"][0], g["smask"][0])
     assert list(labels) == list(l2) == list(g["labels"])
     assert np.array_equal(ok, ok2) and np.array_equal(ok, g["valid"])
+
+
+def test_pipeline_host_helpers():
+    """vstnet_amd.pipeline: the background frame source and the background sink (pure host logic; the GPU part is
+    covered by test_frame_pipeline_matches_sequential)."""
+    import time
+    import numpy as np
+    import pytest
+    from vstnet_amd.pipeline import prefetch, AsyncSink, FramePipeline
+
+    assert list(prefetch(iter(range(10)), ahead=3)) == list(range(10))
+    assert list(prefetch(iter([]), ahead=1)) == []
+
+    def bad_source():
+        yield 1
+        raise ValueError("decode failed")
+    it = prefetch(bad_source(), ahead=2)
+    assert next(it) == 1
+    with pytest.raises(ValueError, match="decode failed"):
+        next(it)
+
+    got = []
+    sink = AsyncSink(lambda i, a: (time.sleep(0.001), got.append((i, int(a.sum()))))[1], ahead=2)
+    buf = np.zeros((4, 4, 3), dtype=np.uint8)
+    for i in range(6):
+        buf[:] = i                      # the sink must have copied the slot before it is overwritten
+        sink(i, buf)
+    sink.close()
+    assert got == [(i, i * 48) for i in range(6)]
+
+    def bad_write(i, a):
+        raise OSError("disk full")
+    sink = AsyncSink(bad_write)
+    sink(0, buf)
+    with pytest.raises(OSError, match="disk full"):
+        sink.close()
+
+    if not __import__("torch").cuda.is_available():
+        with pytest.raises(RuntimeError, match="needs the GPU"):
+            FramePipeline(None, None, 64, 64)
