@@ -98,11 +98,18 @@ def main():
     with torch.no_grad():
         z_s = net(style)
         s_stats = cw.style_stats(z_s)
+        plan = None
+        if args.masked and not args.recompute_style:      # the masks and the style do not change between frames
+            plan = cw.bind_style(cw.plan_masks(cmask, smask, (fpg,) + tuple(z_s.shape[1:]), (fpg,) + tuple(z_s.shape[1:]), dev),
+                                 z_s.expand(fpg, -1, -1, -1))
 
         def stylize_batch():
             z_c = net(content, forward=True)
-            if args.masked:
-                z_cs = cw.transfer(z_c, z_s.expand(fpg, -1, -1, -1), cmask, smask)
+            if args.masked and plan is not None:
+                z_cs = cw.transfer_with_plan(z_c, None, plan)
+            elif args.masked:
+                zs = net(style, forward=True)
+                z_cs = cw.transfer(z_c, zs.expand(fpg, -1, -1, -1), cmask, smask)
             elif args.recompute_style:
                 zs = net(style, forward=True)
                 z_cs = cw.transfer(z_c, zs.expand(fpg, -1, -1, -1))

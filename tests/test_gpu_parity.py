@@ -664,3 +664,27 @@ def test_network_vs_oracle_seeded_shapes():
             assert_close(z, zr, TIGHT, f"{mode} {B}x{H}x{W} forward")
             zp = zr + 0.02 * torch.randn(zr.shape, generator=torch.Generator().manual_seed(case))
             assert_close(net(zp.cuda(), forward=False), cpu_ref.revnet_inverse(zp, sd, sp), TIGHT, f"{mode} {B}x{H}x{W} inverse")
+
+
+def test_mask_plan_equals_transfer():
+    """plan_masks / bind_style / transfer_with_plan (masks and style fixed over a clip) == transfer(masks), bit for bit"""
+    from models.cWCT import cWCT
+    net, sd, sp = make_net("photo")
+    cw = cWCT()
+    B, H, W = 2, 48, 64
+    cm = np.stack([synthetic_mask(H, W, 3, seed=1), synthetic_mask(H, W, 4, seed=2)])
+    sm = np.stack([synthetic_mask(40, 56, 4, seed=3, speck=False)] * 2)
+    with torch.no_grad():
+        zs = net(synthetic_frames(1, 40, 56, seed=9).cuda()).expand(B, -1, -1, -1)
+        plan = cw.plan_masks(cm, sm, (B, 32, H, W), zs.shape, zs.device)
+        assert plan.labels[0] == [0, 1, 2] and plan.labels[1] == [0, 1, 2, 3]          # specks and missing labels dropped
+        bound = cw.bind_style(cw.plan_masks(cm, sm, (B, 32, H, W), zs.shape, zs.device), zs)
+        for seed in (4, 5):
+            zc = net(synthetic_frames(B, H, W, seed=seed).cuda())
+            ref = cw.transfer(zc.clone(), zs, cm, sm)
+            assert torch.equal(cw.transfer_with_plan(zc.clone(), zs, plan), ref)
+            assert torch.equal(cw.transfer_with_plan(zc.clone(), None, bound), ref)
+        with pytest.raises(ValueError):
+            cw.transfer_with_plan(zc[:, :, :32], zs, plan)
+        with pytest.raises(ValueError):
+            cw.transfer_with_plan(zc, None, plan)

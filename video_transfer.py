@@ -115,13 +115,18 @@ def main(argv=None):
         first = img_resize(frames[lo], args.max_size, down_scale=net.down_scale)
         content_seg = load_segment(args.content_seg, first.size)[None, ...] if masked else None
         cw_, ch_ = first.size
+        plan = None
+        if masked:      # one label map for every frame and one style: histograms, uploads and the style side happen once
+            with torch.no_grad():
+                zc_shape = (1, 32, ch_, cw_) if net.sp_steps == 2 else (1, 128, ch_ // 2, cw_ // 2)
+                plan = cwct.bind_style(cwct.plan_masks(content_seg, style_seg, zc_shape, z_s.shape, device), z_s)
 
         def transform(z_c, i):
             if args.alpha_c is not None and not masked:
                 assert 0.0 <= args.alpha_c <= 1.0
                 return cwct.interpolation(z_c, styl_feat_list=[z_s], alpha_s_list=[1.0], alpha_c=args.alpha_c)
             if masked:
-                return cwct.transfer(z_c, z_s, content_seg, style_seg)
+                return cwct.transfer_with_plan(z_c, None, plan)
             return cwct.transfer_with_stats(z_c, s_stats)
 
         decode = None

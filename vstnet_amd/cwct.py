@@ -31,6 +31,14 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+class MaskPlan:
+    """What the masked transfer derives from the label maps alone (cWCT.plan_masks); optionally the per-label style
+    statistics (cWCT.bind_style)."""
+
+    def __init__(self):
+        self.cm, self.sm, self.labels, self.shapes, self.style = [], [], [], None, None
+
+
 class cWCT(nn.Module):
     """Cholesky decomposition based WCT (HIP implementation)."""
 
@@ -166,12 +174,17 @@ class cWCT(nn.Module):
 
     def _transfer_seg(self, content_feat, style_feat, cmask, smask):
         """models/cWCT.py:49-109."""
-        B, N, cH, cW = content_feat.shape
-        _, _, sH, sW = style_feat.shape
-        in_dtype = content_feat.dtype
-        c = self._prep(content_feat).reshape(B, N, -1)
-        s = self._prep(style_feat).reshape(B, N, -1)
-        out = c.clone()
+        plan = self.plan_masks(cmask, smask, content_feat.shape, style_feat.shape, content_feat.device)
+        return self.transfer_with_plan(content_feat, style_feat, plan)
+
+    # ------------------------------------------------------------------ cached-mask extension (video: same masks every frame)
+    def plan_masks(self, cmask, smask, content_shape, style_shape, device):
+        """Everything `_transfer_seg` derives from the label maps alone (models/cWCT.py:72-76,166-189): validated /
+        resized uint8 maps on the device and the list of valid labels per sample.  A video loop whose masks do not
+        change builds this once (the reference redoes the host histograms and uploads for every frame)."""
+        B, N, cH, cW = content_shape
+        _, _, sH, sW = style_shape
+        plan = MaskPlan()
         for b in range(B):
             cm_np, sm_np = np.asarray(cmask[b]), np.asarray(smask[b])
             if self.resize_masks:
@@ -185,15 +198,52 @@ class cWCT(nn.Module):
             if cm_np.max() > 255 or sm_np.max() > 255 or cm_np.min() < 0 or sm_np.min() < 0:
                 raise ValueError("labels must be in [0, 255]")
             label_set, label_indicator = self.compute_label_info(cm_np, sm_np)
-            cm = torch.from_numpy(np.ascontiguousarray(cm_np.reshape(-1).astype(np.uint8))).to(c.device)
-            sm = torch.from_numpy(np.ascontiguousarray(sm_np.reshape(-1).astype(np.uint8))).to(c.device)
-            for label in label_set:
-                if not label_indicator[label]:
-                    continue
-                cs = self.stats(c[b], cm, int(label))
-                ss = self.stats(s[b], sm, int(label))
+            plan.cm.append(torch.from_numpy(np.ascontiguousarray(cm_np.reshape(-1).astype(np.uint8))).to(device))
+            plan.sm.append(torch.from_numpy(np.ascontiguousarray(sm_np.reshape(-1).astype(np.uint8))).to(device))
+            plan.labels.append([int(l) for l in label_set if label_indicator[l]])
+        plan.shapes = (tuple(content_shape), tuple(style_shape))
+        return plan
+
+    def bind_style(self, plan, style_feat):
+        """Per-label statistics of the style code, Cholesky-factored once (the masked counterpart of style_stats):
+        transfer_with_plan then skips the style side for every later frame.  Rebind when the style code changes."""
+        B, N = style_feat.shape[:2]
+        if tuple(style_feat.shape) != plan.shapes[1]:
+            raise ValueError(f"plan was made for a style code of shape {plan.shapes[1]}, got {tuple(style_feat.shape)}")
+        s = self._prep(style_feat).reshape(B, N, -1)
+        plan.style = []
+        for b in range(B):
+            per_label = {}
+            for label in plan.labels[b]:
+                st = self.stats(s[b], plan.sm[b], label)
+                info = torch.zeros(1, dtype=torch.int32, device=st.device)
+                with torch.cuda.device(st.device):
+                    _lib.check(_lib.lib().vst_cwct_prefactor(_ptr(st), N, float(self.eps), _ptr(st), _ptr(info), _stream_ptr()),
+                               "vst_cwct_prefactor")
+                per_label[label] = st
+            plan.style.append(per_label)
+        return plan
+
+    def transfer_with_plan(self, content_feat, style_feat, plan):
+        """transfer(content, style, cmask, smask) with the mask work given as plan_masks(...) (and, after bind_style,
+        the style side too; style_feat may then be None)."""
+        B, N, cH, cW = content_feat.shape
+        if tuple(content_feat.shape) != plan.shapes[0]:
+            raise ValueError(f"plan was made for a content code of shape {plan.shapes[0]}, got {tuple(content_feat.shape)}")
+        in_dtype = content_feat.dtype
+        c = self._prep(content_feat).reshape(B, N, -1)
+        s = None
+        if plan.style is None:
+            if style_feat is None or tuple(style_feat.shape) != plan.shapes[1]:
+                raise ValueError("transfer_with_plan needs the style code the plan was made for (or bind_style first)")
+            s = self._prep(style_feat).reshape(B, N, -1)
+        out = c.clone()
+        for b in range(B):
+            for label in plan.labels[b]:
+                cs = self.stats(c[b], plan.cm[b], label)
+                ss = plan.style[b][label] if plan.style is not None else self.stats(s[b], plan.sm[b], label)
                 affine = self.factor(cs, [ss], [1.0], 0.0, N)
-                self.apply(c[b], affine, out=out[b], mask=cm, label=int(label))
+                self.apply(c[b], affine, out=out[b], mask=plan.cm[b], label=label)
         return out.to(in_dtype).reshape(B, N, cH, cW)
 
     # ------------------------------------------------------------------ helpers (public by convention)
