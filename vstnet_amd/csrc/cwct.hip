@@ -128,12 +128,12 @@ __global__ __launch_bounds__(256) void cwct_stats_mfma_kernel(const float* __res
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (VEC) {
                 if (p < p_end) {                          // p_end, L and p are multiples of 4 here
-                    v = *(const float4*)(x + (size_t)c * L + p);
                     m = 0xf;
                     if (mask != nullptr) {
                         const uchar4 mk = *(const uchar4*)(mask + p);
                         m = (mk.x == label) | ((mk.y == label) << 1) | ((mk.z == label) << 2) | ((mk.w == label) << 3);
                     }
+                    if (m) v = *(const float4*)(x + (size_t)c * L + p);     // pixels of other labels are never fetched
                 }
             } else {
                 float t[4] = {0.f, 0.f, 0.f, 0.f};
@@ -157,7 +157,20 @@ __global__ __launch_bounds__(256) void cwct_stats_mfma_kernel(const float* __res
     float asum = 0.f, cnt = 0.f;                       // row sum of channel tid (tid < N); pixel count (channel-0 owners)
     prefetch(p_begin);
     for (long p0 = p_begin; p0 < p_end; p0 += PT) {
-        __syncthreads();                               // previous tile's MFMAs are done with xs
+        // barrier: the previous tile's MFMAs are done with xs.  With a mask it also tells whether this 64-pixel tile holds
+        // any pixel of the label at all: the per-label passes of a masked transfer skip everything else (a region's
+        // tiles are mostly single-label, so K label passes cost about one pass)
+        if (mask != nullptr) {
+            unsigned anym = 0;
+#pragma unroll
+            for (int it = 0; it < NV; ++it) anym |= pm[it];
+            if (!__syncthreads_or((int)anym)) {
+                if (p0 + PT < p_end) prefetch(p0 + PT);
+                continue;
+            }
+        } else {
+            __syncthreads();
+        }
 #pragma unroll
         for (int it = 0; it < NV; ++it) {
             const int e = it * 256 + tid, c = e >> 4, pl = 4 * (e & 15);
