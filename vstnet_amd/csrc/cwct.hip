@@ -336,39 +336,63 @@ __device__ __forceinline__ void fac_load(const double* stats, int tries, float e
         }
 }
 
+// One barrier per column ("look-ahead"): the phase that applies column j's rank-1 update also publishes the UNSCALED
+// column j+1 (diagonal included) in the other half of `col` (2N floats); after the barrier every thread takes the pivot
+// sqrt(col[j+1]) and the scaled entries it needs itself.  Same divisions and products as the two-barrier form.
 template <int BLK>
 __device__ bool fac_chol(float (&r)[BLK][BLK], int ti, int tj, float* col, float* s_piv, int* s_flag) {
+    constexpr int N = 16 * BLK;
+    (void)s_piv; (void)s_flag;
+    __syncthreads();                                        // a previous factorisation may still be reading col
+    if (tj == 0) {
+#pragma unroll
+        for (int a = 0; a < BLK; ++a) col[ti + 16 * a] = r[a][0];
+    }
     __syncthreads();
-    if (ti == 0 && tj == 0) *s_flag = 0;
-    __syncthreads();
+    int p = 0;
 #pragma unroll
     for (int jb = 0; jb < BLK; ++jb) {
 #pragma unroll 1
         for (int jj = 0; jj < 16; ++jj) {
             const int j = 16 * jb + jj;
-            if (ti == jj && tj == jj) {
-                const float d = r[jb][jb];
-                if (!(d > 0.f)) *s_flag = 1; else *s_piv = sqrtf(d);
-            }
-            __syncthreads();
-            if (*s_flag) return true;                       // uniform
-            const float piv = *s_piv;
+            const float* cu = col + p * N;
+            const float d = cu[j];
+            if (!(d > 0.f)) return true;                    // uniform: every thread reads the same word
+            const float piv = sqrtf(d);
+            const float rpiv = 1.0f / piv;                  // LAPACK's potf2 scales the column by 1/ajj as well
+            float li[BLK], lk[BLK];
+#pragma unroll
+            for (int a = jb; a < BLK; ++a) li[a] = cu[ti + 16 * a] * rpiv;
+#pragma unroll
+            for (int b = jb; b < BLK; ++b) lk[b] = cu[tj + 16 * b] * rpiv;
             if (tj == jj) {
 #pragma unroll
                 for (int a = jb; a < BLK; ++a) {
                     const int i = ti + 16 * a;
-                    if (i > j) { r[a][jb] = r[a][jb] / piv; col[i] = r[a][jb]; }
-                    else if (i == j) { r[a][jb] = piv; col[i] = piv; }
+                    if (i > j) r[a][jb] = li[a];
+                    else if (i == j) r[a][jb] = piv;
                 }
             }
-            __syncthreads();
 #pragma unroll
             for (int a = jb; a < BLK; ++a)
 #pragma unroll
                 for (int b = jb; b < BLK; ++b) {
                     const int i = ti + 16 * a, k = tj + 16 * b;
-                    if (i > j && k > j && k <= i) r[a][b] -= col[i] * col[k];
+                    if (i > j && k > j && k <= i) r[a][b] -= li[a] * lk[b];
                 }
+            // publish the next column, unscaled (its owner threads have just finished updating it)
+            const int jn = j + 1;
+            if (jn < N && tj == (jn & 15)) {
+                float* cn = col + (p ^ 1) * N;
+#pragma unroll
+                for (int a = jb; a < BLK; ++a) {
+                    const int i = ti + 16 * a;
+                    const float v = jj < 15 ? r[a][jb] : r[a][jb + 1 < BLK ? jb + 1 : jb];
+                    if (i >= jn) cn[i] = v;
+                }
+            }
+            __syncthreads();
+            p ^= 1;
         }
     }
 #pragma unroll
@@ -450,30 +474,27 @@ __global__ __launch_bounds__(256) void cwct_factor_kernel(const FactorArgs a) {
         for (int b = 0; b < BLK; ++b) Lmat[(ti + 16 * a2) * N + tj + 16 * b] = r[a2][b];
     __syncthreads();
     // ---- solve T * Lc = mixL in place (m := T), last column first; T stays lower triangular ---------------------------
-    int par = 0;
+    // Row i of T depends on row i of mixL only, and a row's 16 column owners (tj = 0..15) are 16 consecutive lanes of
+    // one wave: the column value travels by a 16-lane shuffle and Lc is read-only in LDS, so the whole solve needs no
+    // barrier (it was one barrier per column: 140 of the kernel's 240 us at N = 128).
 #pragma unroll
     for (int jb = BLK - 1; jb >= 0; --jb) {
 #pragma unroll 1
         for (int jj = 15; jj >= 0; --jj) {
             const int j = 16 * jb + jj;
-            if (tj == jj) {
-                const float ljj = Lmat[j * N + j];
+            const float rljj = 1.0f / Lmat[j * N + j];
+            float lrow[BLK];
 #pragma unroll
-                for (int a2 = 0; a2 < BLK; ++a2) {
-                    const float t = m[a2][jb] / ljj;
-                    m[a2][jb] = t;
-                    tcol[par * N + ti + 16 * a2] = t;
-                }
+            for (int b = 0; b <= jb; ++b) lrow[b] = Lmat[j * N + tj + 16 * b];
+#pragma unroll
+            for (int a2 = 0; a2 < BLK; ++a2) {
+                const float mine = m[a2][jb] * rljj;             // meaningful in lane tj == jj
+                const float t = __shfl(mine, jj, 16);
+                if (tj == jj) m[a2][jb] = t;
+#pragma unroll
+                for (int b = 0; b <= jb; ++b)
+                    if (tj + 16 * b < j) m[a2][b] -= t * lrow[b];
             }
-            __syncthreads();
-#pragma unroll
-            for (int a2 = 0; a2 < BLK; ++a2)
-#pragma unroll
-                for (int b = 0; b <= jb; ++b) {
-                    const int k = tj + 16 * b;
-                    if (k < j) m[a2][b] -= tcol[par * N + ti + 16 * a2] * Lmat[j * N + k];
-                }
-            par ^= 1;
         }
     }
     // ---- t0 = mix_mean - T * mean_c (reduce over the 16 threads of a row: contiguous lanes), write {T, t0} ----------
@@ -494,7 +515,7 @@ __global__ __launch_bounds__(256) void cwct_factor_kernel(const FactorArgs a) {
 template <int BLK>
 __global__ __launch_bounds__(256) void cwct_prefactor_kernel(const double* stats, float eps, double* out, int* info) {
     constexpr int N = 16 * BLK;
-    __shared__ float col[N];
+    __shared__ float col[2 * N];
     __shared__ float s_piv;
     __shared__ int s_flag;
     const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
