@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--recompute-style", action="store_true", help="re-encode + re-factor the style every frame "
                     "(the reference's video loop, video_transfer.py:195) instead of caching it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inplace-cwct", action="store_true", help="overwrite the content code with the transferred code")
     ap.add_argument("--host-pipeline", type=int, default=0, metavar="FRAMES", help="also time FRAMES uint8 frames that "
                     "start and end in host memory through vstnet_amd.pipeline.FramePipeline (PCIe-inclusive rate; "
                     "reported as an extra field, never as `value`)")
@@ -114,7 +115,7 @@ def main():
                 zs = net(style, forward=True)
                 z_cs = cw.transfer(z_c, zs.expand(fpg, -1, -1, -1))
             else:
-                z_cs = cw.transfer_with_stats(z_c, s_stats)
+                z_cs = cw.transfer_with_stats(z_c, s_stats, inplace=args.inplace_cwct)
             return net(z_cs, forward=False)
 
         # every step is one independent batch; consecutive steps alternate over `--streams` HIP streams so that

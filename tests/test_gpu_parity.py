@@ -688,3 +688,16 @@ def test_mask_plan_equals_transfer():
             cw.transfer_with_plan(zc[:, :, :32], zs, plan)
         with pytest.raises(ValueError):
             cw.transfer_with_plan(zc, None, plan)
+
+
+def test_transfer_with_stats_inplace():
+    from models.cWCT import cWCT
+    net, sd, sp = make_net("photo")
+    cw = cWCT()
+    with torch.no_grad():
+        stats = cw.style_stats(net(synthetic_frames(1, 40, 56, seed=9).cuda()))
+        zc = net(synthetic_frames(2, 48, 64, seed=3).cuda())
+        ref = cw.transfer_with_stats(zc, stats)
+        keep = zc.clone()
+        out = cw.transfer_with_stats(zc, stats, inplace=True)
+        assert out.data_ptr() == zc.data_ptr() and torch.equal(out, ref) and not torch.equal(zc, keep)

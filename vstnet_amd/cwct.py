@@ -160,12 +160,14 @@ class cWCT(nn.Module):
             out.append(st)
         return out
 
-    def transfer_with_stats(self, content_feat, style_stats, alpha_c=0.0):
-        """transfer(content, style) with the style side given as style_stats(style) (len B or 1)."""
+    def transfer_with_stats(self, content_feat, style_stats, alpha_c=0.0, inplace=False):
+        """transfer(content, style) with the style side given as style_stats(style) (len B or 1).  inplace=True
+        overwrites a contiguous fp32 content code instead of allocating the result (like the reference's masked path,
+        cWCT.py:62,103; one 128 MiB buffer less per 1024x1024 frame in flight)."""
         B, N, cH, cW = content_feat.shape
         in_dtype = content_feat.dtype
         c = self._prep(content_feat).reshape(B, N, -1)
-        out = torch.empty_like(c)
+        out = c if inplace and c.data_ptr() == content_feat.data_ptr() else torch.empty_like(c)
         for b in range(B):
             ss = style_stats[b if len(style_stats) > 1 else 0]
             affine = self.factor(self.stats(c[b]), [ss], [1.0], alpha_c, N)
