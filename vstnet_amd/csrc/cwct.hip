@@ -656,6 +656,100 @@ __global__ __launch_bounds__(256) void cwct_apply_mfma_kernel(const float* x, fl
     }
 }
 
+// Unmasked apply for N >= 64 on the bf16 matrix cores with split operands (the same "bf16x3" arithmetic as the
+// convs: T = Th + Tl, x = xh + xl, y += Th*xl + Tl*xh + Th*xh, fp32 accumulate): the fp32 MFMA form is bound by the
+// 32x32x2 instruction's throughput at N = 128 (8.6 GFLOP per 512x512 code -> 63 us at best, 152 measured), this one by
+// HBM.  T's fragments are pre-split once per workgroup into LDS; a wave takes 64 pixels per iteration (16 lanes x 4
+// consecutive pixels, float4 loads and stores along pixels), four interleaved 16-pixel B operands.
+template <int N>
+__global__ __launch_bounds__(256, 2) void cwct_apply_split_kernel(const float* x, float* y, long L,
+                                                                  const float* __restrict__ affine, long niter) {
+    constexpr int MB = N / 16, KS = N / 32;
+    constexpr int PQ = N >= 128 ? 2 : 4;                     // interleaved 16-pixel sets per wave (accumulators: PQ*MB*4 VGPRs)
+    typedef __attribute__((ext_vector_type(PQ))) float fvec;
+    extern __shared__ __attribute__((aligned(16))) unsigned char asm2_[];
+    uint4* const th = (uint4*)asm2_;                        // [MB][KS][4 kg][16 lrow] fragments of 8 bf16
+    uint4* const tl = th + MB * KS * 64;
+    float* const t0 = (float*)(tl + MB * KS * 64);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int f = tid; f < MB * KS * 64; f += 256) {
+        const int lrow = f & 15, kg = (f >> 4) & 3, ks = (f >> 6) % KS, m = (f >> 6) / KS;
+        const float* src = affine + (size_t)(16 * m + lrow) * N + 32 * ks + 8 * kg;
+        bf16x8 h, l;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float v = src[i];
+            h[i] = (__bf16)v;
+            l[i] = (__bf16)(v - (float)h[i]);
+        }
+        th[f] = __builtin_bit_cast(uint4, h);
+        tl[f] = __builtin_bit_cast(uint4, l);
+    }
+    for (int i = tid; i < N; i += 256) t0[i] = affine[N * N + i];
+    __syncthreads();
+    const int n16 = lane & 15, kg = lane >> 4;
+    for (long it = (long)blockIdx.x * 4 + wave; it < niter; it += (long)gridDim.x * 4) {
+        const long p = it * (16 * PQ) + PQ * n16;            // L % (16 PQ) == 0 (launch condition)
+        f32x4 acc[PQ][MB];
+#pragma unroll
+        for (int q = 0; q < PQ; ++q)
+#pragma unroll
+            for (int m = 0; m < MB; ++m) acc[q][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1                                             // keep one k-step's loads in flight, not all of them
+        for (int ks = 0; ks < KS; ++ks) {
+            fvec v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = *(const fvec*)(x + (size_t)(32 * ks + 8 * kg + c) * L + p);
+            bf16x8 xh[PQ], xl[PQ];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int q = 0; q < PQ; ++q) {
+                    xh[q][c] = (__bf16)v[c][q];
+                    xl[q][c] = (__bf16)(v[c][q] - (float)xh[q][c]);
+                }
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                const bf16x8 wh = __builtin_bit_cast(bf16x8, th[(m * KS + ks) * 64 + kg * 16 + n16]);
+                const bf16x8 wl = __builtin_bit_cast(bf16x8, tl[(m * KS + ks) * 64 + kg * 16 + n16]);
+#pragma unroll
+                for (int q = 0; q < PQ; ++q) {
+                    acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[q], acc[q][m], 0, 0, 0);
+                    acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[q], acc[q][m], 0, 0, 0);
+                    acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[q], acc[q][m], 0, 0, 0);
+                }
+            }
+        }
+        // lane (n16, kg) holds output channels 16m + 4kg + r of pixels p + q
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 16 * m + 4 * kg + r;
+                const float b = t0[co];
+                fvec o;
+#pragma unroll
+                for (int q = 0; q < PQ; ++q) o[q] = acc[q][m][r] + b;
+                *(fvec*)(y + (size_t)co * L + p) = o;
+            }
+    }
+}
+
+template <int N>
+static int launch_apply_split(const float* x, float* y, long L, const float* affine, hipStream_t st) {
+    constexpr int MB = N / 16, KS = N / 32;
+    const long niter = L / (N >= 128 ? 32 : 64);
+    long wgs = (niter + 3) / 4;
+    if (wgs > 2048) wgs = 2048;
+    const size_t lds = (size_t)2 * MB * KS * 64 * 16 + N * sizeof(float);
+    auto kern = cwct_apply_split_kernel<N>;
+    static unsigned attr_done = 0;
+    if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)lds, &attr_done)) return rc_;
+    kern<<<dim3((unsigned)wgs), 256, lds, st>>>(x, y, L, affine, niter);
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
 template <int NBLK, int PXV>
 static int launch_apply_mfma(const float* x, float* y, long L, const float* affine, const uint8_t* mask, int label,
                              hipStream_t st) {
@@ -672,9 +766,14 @@ static int launch_apply_mfma(const float* x, float* y, long L, const float* affi
     return VST_OK;
 }
 
+#ifndef VST_APPLY_SPLIT_MIN_N
+#define VST_APPLY_SPLIT_MIN_N 64
+#endif
 template <int N>
 static int launch_apply(const float* x, float* y, long L, const float* affine, const uint8_t* mask, int label,
                         hipStream_t st) {
+    if (N >= VST_APPLY_SPLIT_MIN_N && mask == nullptr && (L % 64) == 0 && (((uintptr_t)x | (uintptr_t)y) % 16) == 0)
+        return launch_apply_split<(N >= 32 ? N : 32)>(x, y, L, affine, st);
     if (N >= 32) {                                           // matrix-core path (needs vector-aligned rows)
         constexpr int PXM = N == 32 ? 4 : 2;
         if ((L % PXM) == 0 && L >= PXM && (((uintptr_t)x | (uintptr_t)y) % (4 * PXM)) == 0)
