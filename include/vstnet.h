@@ -40,6 +40,9 @@ extern "C" {
 /* conv arithmetic */
 #define VST_PREC_BF16X3 0   /* bf16 MFMA, hi/lo split operands (3 products), fp32 accumulate: ~3e-6 rel */
 #define VST_PREC_FP32 1     /* plain fp32 FMA direct convolution (diagnostic / cross-check, slow) */
+#define VST_PREC_F16X2 2    /* as BF16X3, except the 256-channel stride-1 blocks (75 % of the flops): fp16 MFMA,
+                               w_hi * (x_hi + x_lo) (2 products; weights rounded to fp16 once), operands pre-split in
+                               HBM and staged by LDS-DMA: ~9e-5 rel on the code, ~3e-6 on a stylised frame */
 
 #define VST_NUM_BLOCKS 32   /* 30 stack blocks + 2 channel_reduction blocks */
 
@@ -49,7 +52,8 @@ const char* vst_error_string(int code);
 /* ---------------------------------------------------------------------------------------------
  * Weights.  A residual_block (models/RevResNet.py:68-94) has three 3x3 convs (conv.1, conv.4,
  * conv.7).  vst_conv_packed_bytes/vst_pack_conv turn one OIHW fp32 weight tensor (device) into the
- * packed form the kernels read: [fp32 taps-major copy | bf16 hi fragments | bf16 lo fragments].
+ * packed form the kernels read: [fp32 taps-major copy | bf16 hi fragments | bf16 lo fragments
+ * | for cin, cout >= 64: fp16 fragments in the K order of the LDS-DMA kernels].
  * ------------------------------------------------------------------------------------------- */
 size_t vst_conv_packed_bytes(int cout, int cin);
 int vst_pack_conv(const float* w_oihw, int cout, int cin, void* packed, void* stream);
@@ -148,7 +152,8 @@ int vst_cwct_prefactor(const double* stats, int N, float eps, double* out, int* 
 
 /* ---------------------------------------------------------------------------------------------
  * Measurement hook (bench.py's live roofline figure): bracket every launch of one conv kernel class
- * with HIP events on the launch stream.  Not thread-safe; one profiling session at a time.
+ * with HIP events on the launch stream.  One profiling session at a time (begin/end and the launch
+ * sites are serialised by a lock, so other host threads may keep launching while a session runs).
  *   vst_profile_begin(VST_KERNEL_ID(cin,cout,stride), max_records); ...run passes...;
  *   vst_profile_end(&total_ms, &launches)   (synchronises on the recorded events)
  * ------------------------------------------------------------------------------------------- */

@@ -98,9 +98,12 @@ def run_block(L, net, k, channel, stride, direction, precision, dst_nchw, src_nc
     return zc_to_nchw(dst.cpu(), dst_nchw.shape[1])
 
 
-@pytest.mark.parametrize("precision,tol", [(_lib.PREC_FP32, 2e-6), (_lib.PREC_BF16X3, 2e-5)])
+# F16X2 rounds the 256-channel blocks' weights to fp16 (2^-12): ~1e-4 per block on these fixtures; its budget here is 3e-4
+@pytest.mark.parametrize("precision,tol", [(_lib.PREC_FP32, 2e-6), (_lib.PREC_BF16X3, 2e-5), (_lib.PREC_F16X2, 3e-4)])
 @pytest.mark.parametrize("name,k,channel,stride", BLOCKS)
 def test_block_golden(L, golden, name, k, channel, stride, precision, tol):
+    if precision == _lib.PREC_F16X2 and (channel, stride) != (256, 1):
+        pytest.skip("only the 256-channel stride-1 blocks differ from bf16x3 in this mode")
     g = golden("blocks")
     net, sd, _ = make_net("photo")
     x1, x2 = T(g[f"{name}_x1"]), T(g[f"{name}_x2"])
@@ -124,12 +127,15 @@ def test_block_golden(L, golden, name, k, channel, stride, precision, tol):
 
 
 # ------------------------------------------------------------------------------------------- network
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+NET_TOL = {"fp32": 5e-6, "bf16x3": TIGHT, "f16x2": 2e-4}
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x2"])
 @pytest.mark.parametrize("mode", ["photo", "art"])
 def test_network_golden(golden, mode, precision):
     g = golden(f"net_{mode}")
     net, sd, sp = make_net(mode, precision)
-    tol = 5e-6 if precision == "fp32" else TIGHT
+    tol = NET_TOL[precision]
     for tag in ("16", "24x40", "32b2"):
         x = T(g[f"x_{tag}"]).cuda()
         z = net(x, forward=True)

@@ -19,6 +19,7 @@ HEADERS = sorted(glob.glob(os.path.join(PKG_DIR, "csrc", "*.h"))) + [os.path.joi
 NUM_BLOCKS = 32
 PREC_BF16X3 = 0
 PREC_FP32 = 1
+PREC_F16X2 = 2
 
 # every symbol include/vstnet.h declares
 EXPORTS = [

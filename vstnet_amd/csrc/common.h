@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "vstnet.h"
 
 #define VST_RETURN_IF_LAUNCH_FAILED()                      \
@@ -46,14 +47,16 @@ __device__ __forceinline__ int reflect_clamp(int v, int n) {
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is per device: set it once per (kernel, device), not once per process
-static inline int vst_ensure_dynamic_lds(const void* kernel, int bytes, unsigned* done_mask) {
+// (the mask is atomic: entry points may be called from several host threads, one stream each; setting the attribute
+// twice is harmless)
+static inline int vst_ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<unsigned>* done_mask) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
-    if (dev < 32 && (*done_mask >> dev) & 1u) return VST_OK;
+    if (dev < 32 && (done_mask->load(std::memory_order_acquire) >> dev) & 1u) return VST_OK;
     e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
-    if (dev < 32) *done_mask |= 1u << dev;
+    if (dev < 32) done_mask->fetch_or(1u << dev, std::memory_order_release);
     return VST_OK;
 }
 
@@ -61,12 +64,14 @@ static inline bool vst_shape_ok(int B, int H, int W) {
     return B > 0 && H >= 8 && W >= 8 && (H % 4) == 0 && (W % 4) == 0;
 }
 
-// packed conv weights: [fp32 taps-major | bf16 hi frags | bf16 lo frags]
+// packed conv weights: [fp32 taps-major | bf16 hi frags | bf16 lo frags]; the stage-3 shapes (cin, cout >= 64) are
+// followed by the fp16 fragments of conv3.hip in its permuted K order
 struct PackedConvLayout {
     int ksteps;       // number of 32-deep K steps (all chunks)
     int coutp;        // cout padded to a multiple of 16
     size_t f32_bytes; // 9*cin*cout*4 rounded up to 256
-    size_t frag_bytes;// ksteps*4*coutp*16 (per hi / lo section)
+    size_t frag_bytes;// ksteps*4*coutp*16 (per section)
+    int sp_sections;  // 1 for the stage-3 shapes, else 0
 };
 
 __host__ __device__ inline PackedConvLayout packed_conv_layout(int cout, int cin) {
@@ -75,8 +80,25 @@ __host__ __device__ inline PackedConvLayout packed_conv_layout(int cout, int cin
     p.coutp = (cout + 15) / 16 * 16;
     p.f32_bytes = ((size_t)9 * cin * cout * 4 + 255) / 256 * 256;
     p.frag_bytes = (size_t)p.ksteps * 4 * p.coutp * 16;
+    p.sp_sections = (cin >= 64 && cout >= 64) ? 1 : 0;
     return p;
 }
+
+// HIP-event timing of one kernel class (vst_profile_begin / vst_profile_end): a launch site opens a scope around its
+// launch; sessions and records are serialised by a lock inside conv.hip
+int vst_prof_open(int kernel_id, hipStream_t st);
+void vst_prof_close(int rec, hipStream_t st);
+struct vst_prof_scope {
+    int rec;
+    hipStream_t st;
+    vst_prof_scope(int kernel_id, hipStream_t s) : rec(vst_prof_open(kernel_id, s)), st(s) {}
+    ~vst_prof_scope() { if (rec >= 0) vst_prof_close(rec, st); }
+};
+
+// conv3.hip: one 256-channel stride-1 coupling block on the LDS-DMA kernels.  tmp = [h1 | h2 | shadow] (vst_block_tmp_bytes);
+// shadow_valid: tmp's shadow already holds the split planes of src; write_shadow: leave the planes of the new dst there
+int vst3_block256(const vst_block_weights* w, int direction, int precision, float* dst, const float* src, void* tmp,
+                  int shadow_valid, int write_shadow, int B, int H, int W, void* stream);
 
 // internal (not part of the C ABI): input packing with the constant of forward block 0 folded in
 extern "C" int vst_pack_input_k(const float* x, const uint8_t* x_u8, float* s1, float* s2, int B, int C, int H, int W,

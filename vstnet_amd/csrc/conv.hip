@@ -14,6 +14,7 @@
 // [channel-group of 8][slot][8 x bf16] in which the 16 pixels of an MFMA row block are consecutive
 // 16-byte slots (bank-conflict-free ds_read_b128 for every tap shift); weights are pre-packed in
 // fragment order (layout.hip) and copied straight into LDS.
+#include <mutex>
 #include "common.h"
 
 #ifndef VST_ABLATE
@@ -838,11 +839,27 @@ __global__ __launch_bounds__(256) void conv_fp32_kernel(const ConvArgs a, int CI
 }
 
 // ---- optional per-kernel-class timing with HIP events (vst_profile_begin / vst_profile_end) ---------
+// All of it is behind one lock: launch sites on any host thread may open records while a session is active.
 #define VST_PROFILE_MAX_RECORDS 4096
-static int g_prof_kernel = 0;               // 0 = off, else VST_KERNEL_ID(cin, cout, stride)
+static std::mutex g_prof_mu;
+static std::atomic<int> g_prof_kernel{0};   // 0 = off, else VST_KERNEL_ID(cin, cout, stride)
 static int g_prof_count = 0, g_prof_cap = 0;
 static hipEvent_t g_prof_ev[2 * VST_PROFILE_MAX_RECORDS];
 static bool g_prof_ev_created = false;
+
+int vst_prof_open(int kernel_id, hipStream_t st) {
+    if (g_prof_kernel.load(std::memory_order_relaxed) != kernel_id) return -1;     // the common case: no lock taken
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof_kernel.load() != kernel_id || g_prof_count >= g_prof_cap) return -1;
+    const int rec = g_prof_count++;
+    (void)hipEventRecord(g_prof_ev[2 * rec], st);
+    return rec;
+}
+
+void vst_prof_close(int rec, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (rec < g_prof_count) (void)hipEventRecord(g_prof_ev[2 * rec + 1], st);
+}
 
 template <int CIN, int COUT, int STRIDE, bool IN_STATE, bool OUT_STATE>
 static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) {
@@ -854,13 +871,12 @@ static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) 
         VST_RETURN_IF_LAUNCH_FAILED();
         return VST_OK;
     }
-    if (precision != VST_PREC_BF16X3) return VST_E_MODE;
-    const bool timed = g_prof_kernel == VST_KERNEL_ID(CIN, COUT, STRIDE) && g_prof_count < g_prof_cap;
-    if (timed) (void)hipEventRecord(g_prof_ev[2 * g_prof_count], st);
+    if (precision != VST_PREC_BF16X3 && precision != VST_PREC_F16X2) return VST_E_MODE;
+    vst_prof_scope prof(VST_KERNEL_ID(CIN, COUT, STRIDE), st);
     if constexpr (CIN >= 64 && COUT >= 64 && STRIDE == 1) {
         using C = PipeCfg<CIN, COUT>;
         auto kern = conv_pipe_kernel<CIN, COUT, IN_STATE, OUT_STATE>;
-        static unsigned attr_done = 0;
+        static std::atomic<unsigned> attr_done{0};
         if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)(C::LDS_BYTES), &attr_done)) return rc_;
         ConvArgs t = a;
         t.tiles_x = (a.Wout + 15) / 16; t.tiles_y = (a.Hout + 15) / 16; t.tiles_total = t.tiles_x * t.tiles_y * B;
@@ -868,14 +884,13 @@ static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) 
     } else {
         using C = ConvCfg<CIN, COUT, STRIDE>;
         auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, IN_STATE, OUT_STATE>;
-        static unsigned attr_done = 0;
+        static std::atomic<unsigned> attr_done{0};
         if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)(C::LDS_BYTES), &attr_done)) return rc_;
         ConvArgs t = a;
         t.tiles_x = (a.Wout + C::TW - 1) / C::TW; t.tiles_y = (a.Hout + C::TH - 1) / C::TH;
         t.tiles_total = t.tiles_x * t.tiles_y * B * C::NCOT;
         kern<<<dim3((t.tiles_total + 7) / 8 * 8), 256, C::LDS_BYTES, st>>>(t);
     }
-    if (timed) { (void)hipEventRecord(g_prof_ev[2 * g_prof_count + 1], st); ++g_prof_count; }
     VST_RETURN_IF_LAUNCH_FAILED();
     return VST_OK;
 }
@@ -886,15 +901,13 @@ static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) 
 template <int MID, int CH>
 static int launch_pair(const ConvArgs& a, int B, hipStream_t st) {
     using P = PairCfg<MID, CH>;
-    const bool timed = g_prof_kernel == VST_KERNEL_ID(MID, CH, 1) && g_prof_count < g_prof_cap;
-    if (timed) (void)hipEventRecord(g_prof_ev[2 * g_prof_count], st);
+    vst_prof_scope prof(VST_KERNEL_ID(MID, CH, 1), st);
     auto kern = conv_pair_kernel<MID, CH>;
-    static unsigned attr_done = 0;
+    static std::atomic<unsigned> attr_done{0};
     if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)(P::LDS_BYTES), &attr_done)) return rc_;
     ConvArgs t = a;
     t.tiles_x = (a.Wout + 15) / 16; t.tiles_y = (a.Hout + 15) / 16; t.tiles_total = t.tiles_x * t.tiles_y * B;
     kern<<<dim3((t.tiles_total + 7) / 8 * 8), 256, P::LDS_BYTES, st>>>(t);
-    if (timed) { (void)hipEventRecord(g_prof_ev[2 * g_prof_count + 1], st); ++g_prof_count; }
     VST_RETURN_IF_LAUNCH_FAILED();
     return VST_OK;
 }
@@ -920,7 +933,7 @@ static int run_block(const vst_block_weights* w, int direction, int precision, f
     int rc = launch_conv<IN_CH, MID, STRIDE, true, false>(a, B, precision, st);
     if (rc) return rc;
     if constexpr (CH <= 64 && VST_PAIR) {
-        if (precision == VST_PREC_BF16X3) {       // conv.4 + conv.7 in one launch, h2 stays in LDS
+        if (precision != VST_PREC_FP32) {         // conv.4 + conv.7 in one launch, h2 stays in LDS
             a.in = h1; a.out = dst; a.Hin = Ho; a.Win = Wo; a.in_img_stride = mid_img; a.out_img_stride = state_img;
             a.packed = (const unsigned char*)w->conv[2].packed; a.bias = w->conv[2].bias;
             a.packed1 = (const unsigned char*)w->conv[1].packed; a.bias1 = w->conv[1].bias;
@@ -950,6 +963,7 @@ extern "C" {
 int vst_profile_begin(int kernel_id, int max_records) {
     if (kernel_id <= 0 || max_records <= 0) return VST_E_ARG;
     if (max_records > VST_PROFILE_MAX_RECORDS) max_records = VST_PROFILE_MAX_RECORDS;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof_ev_created) {
         for (int i = 0; i < 2 * VST_PROFILE_MAX_RECORDS; ++i) {
             hipError_t e = hipEventCreate(&g_prof_ev[i]);
@@ -957,12 +971,15 @@ int vst_profile_begin(int kernel_id, int max_records) {
         }
         g_prof_ev_created = true;
     }
-    g_prof_kernel = kernel_id; g_prof_count = 0; g_prof_cap = max_records;
+    g_prof_count = 0; g_prof_cap = max_records;
+    g_prof_kernel.store(kernel_id);
     return VST_OK;
 }
 
 int vst_profile_end(double* total_ms, int* launches) {
     if (!total_ms || !launches) return VST_E_ARG;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_kernel.store(0);
     double tot = 0.0;
     for (int i = 0; i < g_prof_count; ++i) {
         hipError_t e = hipEventSynchronize(g_prof_ev[2 * i + 1]);
@@ -973,11 +990,12 @@ int vst_profile_end(double* total_ms, int* launches) {
         tot += ms;
     }
     *total_ms = tot; *launches = g_prof_count;
-    g_prof_kernel = 0; g_prof_count = 0; g_prof_cap = 0;
+    g_prof_count = 0; g_prof_cap = 0;
     return VST_OK;
 }
 
-size_t vst_block_tmp_bytes(int B, int H, int W) { return (size_t)B * H * W * 8 * sizeof(float); }
+// h1 + h2 (8 floats per pixel) + the split-plane shadow of one state half for the stage-3 kernels of conv3.hip (16)
+size_t vst_block_tmp_bytes(int B, int H, int W) { return (size_t)B * H * W * 24 * sizeof(float); }
 
 int vst_block_apply(const vst_block_weights* w, int channel, int stride, int direction, int precision,
                     float* dst, const float* src, void* tmp, int B, int H, int W, void* stream) {
@@ -991,18 +1009,22 @@ int vst_block_apply(const vst_block_weights* w, int channel, int stride, int dir
     if (channel == 16 && stride == 1) return run_block<16, 1>(w, direction, precision, dst, src, t, B, H, W, st);
     if (channel == 64 && stride == 1) return run_block<64, 1>(w, direction, precision, dst, src, t, B, H, W, st);
     if (channel == 64 && stride == 2) return run_block<64, 2>(w, direction, precision, dst, src, t, B, H, W, st);
-    if (channel == 256 && stride == 1) return run_block<256, 1>(w, direction, precision, dst, src, t, B, H, W, st);
+    if (channel == 256 && stride == 1) {
+        if (precision == VST_PREC_F16X2)
+            return vst3_block256(w, direction, precision, dst, src, tmp, 0, 0, B, H, W, stream);
+        return run_block<256, 1>(w, direction, precision, dst, src, t, B, H, W, st);
+    }
     if (channel == 256 && stride == 2) return run_block<256, 2>(w, direction, precision, dst, src, t, B, H, W, st);
     return VST_E_SHAPE;
 }
 
-size_t vst_pass_workspace_bytes(int B, int H, int W) { return (size_t)B * H * W * (16 + 16 + 8) * sizeof(float); }
+size_t vst_pass_workspace_bytes(int B, int H, int W) { return (size_t)B * H * W * (16 + 16 + 24) * sizeof(float); }
 
 // Images per internal sub-batch: the reversible state + intermediates of a sub-batch (160 B/pixel) should stay in
 // the 256 MiB Infinity Cache between the 96 conv launches of a pass (measured: 8 frames of 1024x1024 in one batch
 // run 27 % slower per frame than one at a time); small images are still batched to fill the chip.
 static int pass_sub_batch(int B, int H, int W) {
-    const size_t per_img = (size_t)H * W * 160;
+    const size_t per_img = (size_t)H * W * 224;
     size_t nb = ((size_t)192 << 20) / per_img;
     if (nb < 1) nb = 1;
     return nb > (size_t)B ? B : (int)nb;
@@ -1016,15 +1038,20 @@ static int revnet_forward_chunk(const vst_net_weights* w, const float* x, const 
     float* tmp = s[1] + (size_t)B * H * W * 16;
     // forward block 0 has x2 = 0: F(0) is a per-channel constant that the pack kernel adds (fp32 diagnostic mode keeps
     // the literal three convolutions)
-    const bool fold0 = precision == VST_PREC_BF16X3;
+    const bool fold0 = precision != VST_PREC_FP32;
     float* k16 = tmp;                                        // 16 floats at the head of the intermediates' scratch
     int rc = fold0 ? vst_block0_const(&w->blocks[0], k16, stream) : VST_OK;
     if (rc) return rc;
     rc = vst_pack_input_k(x, x_u8, s[0], s[1], B, x_u8 ? 3 : C_in, H, W, fold0 ? k16 : nullptr, stream);
     if (rc) return rc;
+    const bool sp = precision == VST_PREC_F16X2;
     for (int k = fold0 ? 1 : 0; k < VST_NUM_BLOCKS; ++k) {
-        rc = vst_block_apply(&w->blocks[k], kBlockChannel[k], kBlockStride[k], +1, precision, s[k & 1], s[1 - (k & 1)],
-                             tmp, B, H, W, stream);
+        if (sp && k >= 21)      // block k's conv.7 leaves the split planes of its dst = block k+1's src
+            rc = vst3_block256(&w->blocks[k], +1, precision, s[k & 1], s[1 - (k & 1)], tmp, k > 21, k < VST_NUM_BLOCKS - 1,
+                               B, H, W, stream);
+        else
+            rc = vst_block_apply(&w->blocks[k], kBlockChannel[k], kBlockStride[k], +1, precision, s[k & 1], s[1 - (k & 1)],
+                                 tmp, B, H, W, stream);
         if (rc) return rc;
     }
     return vst_spread(s[0], s[1], z, B, H, W, sp_steps, stream);
@@ -1038,9 +1065,14 @@ static int revnet_inverse_chunk(const vst_net_weights* w, const float* z, float*
     float* tmp = s[1] + (size_t)B * H * W * 16;
     int rc = vst_gather(z, s[0], s[1], B, H, W, sp_steps, stream);
     if (rc) return rc;
+    const bool sp = precision == VST_PREC_F16X2;
     for (int k = VST_NUM_BLOCKS - 1; k >= 0; --k) {
-        rc = vst_block_apply(&w->blocks[k], kBlockChannel[k], kBlockStride[k], -1, precision, s[k & 1], s[1 - (k & 1)],
-                             tmp, B, H, W, stream);
+        if (sp && k >= 21)
+            rc = vst3_block256(&w->blocks[k], -1, precision, s[k & 1], s[1 - (k & 1)], tmp, k < VST_NUM_BLOCKS - 1, k > 21,
+                               B, H, W, stream);
+        else
+            rc = vst_block_apply(&w->blocks[k], kBlockChannel[k], kBlockStride[k], -1, precision, s[k & 1], s[1 - (k & 1)],
+                                 tmp, B, H, W, stream);
         if (rc) return rc;
     }
     return x_u8 ? vst_unpack_output_u8(s[0], x_u8, B, H, W, stream) : vst_unpack_output(s[0], x, B, C_out, H, W, stream);

@@ -1,0 +1,356 @@
+// Stage-3 / channel_reduction convolutions (64- and 256-channel tensors at quarter resolution, stride 1) fed by LDS-DMA:
+// the VST_PREC_F16X2 path.
+//
+// Reference semantics: residual_block.conv of the 256-channel blocks, models/RevResNet.py:79-88 (ReflectionPad2d(1) +
+// Conv2d 256->64, 64->64, 64->256, ReLU between), used by residual_block.forward/inverse :96-116.
+//
+// These three convs carry 75 % of the network's flops.  Two things differ from the generic kernels of conv.hip:
+//
+//  * Operands arrive already split.  Every activation tensor that one of these kernels reads is kept in HBM as two planes
+//    of fp16 values, hi = round(x), lo = round(x - hi) ("SP" layout: [8-channel group][plane][y][x][8 x fp16], the same
+//    4 bytes per value as fp32), written by the epilogue of the kernel that produced it (the fp32 state of the reversible
+//    network is still what is read-modify-written; its SP copy is a shadow).  The 8 channels of a group are the ones a
+//    producer lane holds, {c0 + 4 kg + r, c0 + 16 + 4 kg + r}; the weights' K order is permuted to match at pack time.
+//    Staging is therefore a plain copy: global_load_lds_dwordx4 (64 lanes x 16 B = 1 KiB of the LDS image per wave
+//    instruction, per-lane source address = reflection padding), no VGPRs, no conversion, no ds_write in the MFMA loop.
+//  * fp16 operands, D += w_hi * (x_hi + x_lo): two MFMAs per product instead of the three of the bf16 split.  The
+//    activations keep 22 bits; the weights are rounded to fp16 once (2^-12 relative), a fixed perturbation of the model that
+//    forward and inverse share.  Measured end to end against the fp64 oracle: 9e-5 on the code, 3e-6 on the stylised frame
+//    (budget 1e-3).
+//
+// Pipeline: a stage = one 32-channel chunk x all 9 taps = 9 k-steps (144 MFMAs per wave) between two barriers.  Both
+// activation-chunk images and two weight-stage buffers live in LDS (156 KB); during stage s the waves issue the DMA of
+// stage s+1's weights and of the next chunk's image, one piece per k-step between the MFMAs, and wait for them (vmcnt(0),
+// by then most of a stage old) in front of the stage's closing raw s_barrier.
+#include <atomic>
+#include "common.h"
+
+#ifndef VST_SP_ABLATE
+#define VST_SP_ABLATE 0      // timing-only builds: 1 = no DMA in the main loop, 2 = no MFMAs, 4 = no fragment re-reads
+#endif
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+struct SpArgs {
+    const unsigned char* in;     // SP planes of the input tensor (image 0)
+    float* state;                // OUT_STATE: fp32 state half that is read-modify-written (ZC layout, level 2)
+    unsigned char* out_sp;       // SP planes written by the epilogue: h1 / h2, or the state's shadow (may be null)
+    const unsigned char* wfrag;  // permuted-K fp16 weight fragments
+    const float* bias;
+    int H, W;                    // quarter-resolution image
+    size_t in_img_bytes, out_img_bytes, state_img_floats;
+    float sign;
+    int tiles_x, tiles_y, tiles_total;
+};
+
+// hi = round(x), lo = round(x - hi); hi saturates at the largest finite fp16 instead of becoming inf
+__device__ __forceinline__ void split8_sp(const float (&f)[8], u32x4& hi, u32x4& lo) {
+    f16x8 h, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h[i] = (_Float16)__builtin_amdgcn_fmed3f(f[i], -65504.f, 65504.f);
+        l[i] = (_Float16)(f[i] - (float)h[i]);
+    }
+    hi = __builtin_bit_cast(u32x4, h);
+    lo = __builtin_bit_cast(u32x4, l);
+}
+
+__device__ __forceinline__ void glds16(const unsigned char* g, unsigned char* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+// byte offset of (8-channel group, plane, y, x) in an SP tensor of an HxW image
+__device__ __forceinline__ size_t sp_offset(int cig, int plane, int y, int x, int H, int W) {
+    return ((((size_t)cig * 2 + plane) * H + y) * W + x) * 16;
+}
+
+template <int N> __device__ __forceinline__ void sp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int CIN, int COUT>
+struct SpCfg {
+    static constexpr int NW = 8;                             // waves, each owning 2 tile rows x 16 pixels x 64 output channels
+    static constexpr int NCHUNK = CIN / 32, NCOT = COUT / 64, Q = NCHUNK * NCOT;
+    static constexpr int MR = 2, TH = NW * MR, IW = 18, NPIX = (TH + 2) * IW;
+    static constexpr int NSLOT = (NPIX + 15) / 16 * 16;      // multiple of 16: the four k-group planes start 256 B apart mod the 256-B bank row
+    static constexpr int A_PLANE = 4 * NSLOT * 16, A_BUF = 2 * A_PLANE;      // [plane][cig][slot][16 B]
+    static constexpr int APIECES = A_BUF / 1024;             // DMA pieces (64 lanes x 16 B) per chunk image (42)
+    static constexpr int APW = (APIECES + NW - 1) / NW;      // per wave (6)
+    static constexpr int WPIECES = 36, WPW = (WPIECES + NW - 1) / NW;        // weight pieces per stage / per wave (5)
+    static constexpr int B_BUF = 9 * 4 * 64 * 16;            // [k][kg][co][16 B] = 36864
+    static constexpr int LDS_BYTES = 2 * A_BUF + 2 * B_BUF;  // 159744
+    static_assert(A_BUF % 1024 == 0 && LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(APW <= 9 && WPW <= 9, "one piece of each kind per k-step");
+};
+
+template <int CIN, int COUT, bool OUT_STATE>
+__global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
+    using C = SpCfg<CIN, COUT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const Abuf = smem;
+    unsigned char* const Bbuf = smem + 2 * C::A_BUF;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 15, kg = lane >> 4;
+    // XCD-aware tile order (see xcd_tile() in conv.hip)
+    int bx, by, b;
+    {
+        const int g = blockIdx.x, per = gridDim.x >> 3;
+        const int n = (g & 7) * per + (g >> 3);
+        if (n >= a.tiles_total) return;
+        bx = n % a.tiles_x;
+        const int r = n / a.tiles_x;
+        by = r % a.tiles_y;
+        b = r / a.tiles_y;
+    }
+    const int tx0 = bx * 16, ty0 = by * C::TH, H = a.H, W = a.W;
+#if VST_SP_ABLATE & 8
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const unsigned char* const in_img = a.in + (size_t)b * a.in_img_bytes;
+    const size_t chunk_bytes = (size_t)128 * H * W;           // 4 channel groups x 2 planes
+
+    // ---- per-lane DMA source offsets ----------------------------------------------------------------------------
+    // The activation image of one chunk (2 planes x 4 groups x NSLOT slots x 16 B) is APIECES pieces of 64 lanes, APW per
+    // wave (pieces past the end repeat the last one: same bytes to the same place); a weight stage is 36 pieces (k, kg).
+    unsigned a_off[C::APW], a_dst[C::APW];
+#pragma unroll
+    for (int u = 0; u < C::APW; ++u) {
+        int i = wave * C::APW + u;
+        i = i > C::APIECES - 1 ? C::APIECES - 1 : i;
+        const int L = i * 64 + lane, pc = L / C::NSLOT;
+        int slot = L - pc * C::NSLOT;
+        slot = slot > C::NPIX - 1 ? C::NPIX - 1 : slot;
+        const int iy = slot / C::IW, ix = slot - iy * C::IW;
+        const int gy = reflect_clamp(ty0 - 1 + iy, H), gx = reflect_clamp(tx0 - 1 + ix, W);
+        a_off[u] = (unsigned)sp_offset(pc & 3, pc >> 2, gy, gx, H, W);
+        a_dst[u] = i * 1024;
+    }
+    unsigned w_off[C::WPW], w_dst[C::WPW];
+#pragma unroll
+    for (int u = 0; u < C::WPW; ++u) {
+        int j = wave * C::WPW + u;
+        j = j > C::WPIECES - 1 ? C::WPIECES - 1 : j;
+        w_off[u] = (unsigned)((j * COUT + lane) * 16);        // j = k*4 + kg
+        w_dst[u] = j * 1024;
+    }
+    // piece u_ of the image of chunk chunk_ / of the weights of stage q_ (into weight buffer q_ & 1)
+#define ISSUE_A1(chunk_, u_) \
+    glds16(in_img + (size_t)(chunk_) * chunk_bytes + a_off[u_], Abuf + ((chunk_) & 1) * C::A_BUF + a_dst[u_])
+#define ISSUE_W1(q_, u_)                                                                                          \
+    {                                                                                                            \
+        const int cot_ = (q_) / C::NCHUNK, chunk_ = (q_) - cot_ * C::NCHUNK;                                     \
+        glds16(a.wfrag + ((size_t)chunk_ * 36 * COUT + cot_ * 64) * 16 + w_off[u_], Bbuf + ((q_) & 1) * C::B_BUF + w_dst[u_]); \
+    }
+
+    // ---- prologue: chunk 0 and the weights of stage 0 ----------------------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < C::APW; ++u) ISSUE_A1(0, u);
+#pragma unroll
+    for (int u = 0; u < C::WPW; ++u) ISSUE_W1(0, u);
+    sp_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    f32x4 acc[C::MR][4];
+#pragma unroll
+    for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int slot_base = (wave * C::MR) * C::IW + lrow;
+    const int oy0 = ty0 + wave * C::MR, ox = tx0 + lrow;
+    const bool full_tile = ty0 + C::TH <= H && tx0 + 16 <= W;
+    float* const st_img = OUT_STATE ? a.state + (size_t)b * a.state_img_floats : nullptr;
+    unsigned char* const sp_img = a.out_sp ? a.out_sp + (size_t)b * a.out_img_bytes : nullptr;
+
+    struct Frags { f16x8 w[4], xh[C::MR], xl[C::MR]; };
+    // k = 3 * dy + dx: tap (dy, dx) of the chunk
+    auto read_frags = [&](Frags& f, const unsigned char* Ab, const unsigned char* Bb, int k) {
+        const int dy = k / 3, dx = k - dy * 3;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) f.w[n] = *(const f16x8*)(Bb + (k * 256 + n * 16) * 16);
+#pragma unroll
+        for (int m = 0; m < C::MR; ++m) {
+            f.xh[m] = *(const f16x8*)(Ab + ((m + dy) * C::IW + dx) * 16);
+            f.xl[m] = *(const f16x8*)(Ab + C::A_PLANE + ((m + dy) * C::IW + dx) * 16);
+        }
+    };
+
+#pragma unroll 1
+    for (int q = 0; q < C::Q; ++q) {
+        const int cot = q / C::NCHUNK, chunk = q - cot * C::NCHUNK;
+        const bool slice_end = chunk == C::NCHUNK - 1;
+        // ---- a slice's last stage: its bias and old state values are fetched first; they are a whole stage old at the
+        //      wait in front of the epilogue ---------------------------------------------------------------------------
+        float4 bias[4], old[C::MR][4];
+        if (slice_end) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bias[n] = *(const float4*)(a.bias + cot * 64 + n * 16 + 4 * kg);
+            if (OUT_STATE) {
+#pragma unroll
+                for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        const bool ok = full_tile || (oy0 + m < H && ox < W);
+                        old[m][n] = ok ? *(const float4*)(st_img + ((size_t)(oy0 + m) * W + ox) * 256 + cot * 64 + n * 16 + 4 * kg)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+            }
+            asm volatile("" ::: "memory");
+        }
+        const bool issue_w = q + 1 < C::Q;                    // next stage's weights -> the buffer stage q-1 used
+        const bool issue_a = q + 1 < C::NCHUNK;               // next chunk's image (first output slice only) -> other image buffer
+        const unsigned char* Ab = Abuf + (chunk & 1) * C::A_BUF + (kg * C::NSLOT + slot_base) * 16;
+        const unsigned char* Bb = Bbuf + (q & 1) * C::B_BUF + (kg * 64 + lrow) * 16;
+        Frags fr[2];
+        read_frags(fr[0], Ab, Bb, 0);
+        // ---- 9 k-steps; fragments double-buffered in registers; one DMA piece of each kind per k-step ----------------------
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (k < 8 && !(VST_SP_ABLATE & 4)) read_frags(fr[(k + 1) & 1], Ab, Bb, k + 1);
+            if (!(VST_SP_ABLATE & 1)) {
+                if (k < C::WPW && issue_w) ISSUE_W1(q + 1, k);
+                if (k < C::APW && issue_a) ISSUE_A1(q + 1, k);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const Frags& f = fr[(VST_SP_ABLATE & 4) ? 0 : (k & 1)];
+            if (VST_SP_ABLATE & 2) {
+                asm volatile("" ::"v"(f.w[0]), "v"(f.w[3]), "v"(f.xh[0]), "v"(f.xl[1]));
+                continue;
+            }
+#pragma unroll
+            for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[n], f.xl[m], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[n], f.xh[m], acc[m][n], 0, 0, 0);
+                }
+        }
+        sp_wait_vm<0>();       // this stage's DMA (issued in its first k-steps) and, at a slice end, bias / old state
+        // ---- epilogue of this 64-channel output slice ----------------------------------------------------------------
+        if (slice_end) {
+#pragma unroll
+            for (int m = 0; m < C::MR; ++m) {
+                const int oy = oy0 + m;
+                const bool ok = full_tile || (oy < H && ox < W);
+                float r[4][4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const float bb[4] = {bias[n].x, bias[n].y, bias[n].z, bias[n].w};
+                    const float oo[4] = {old[m][n].x, old[m][n].y, old[m][n].z, old[m][n].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = acc[m][n][e] + bb[e];
+                        r[n][e] = OUT_STATE ? oo[e] + a.sign * v : (v > 0.f ? v : 0.f);
+                    }
+                    if (OUT_STATE && ok)
+                        *(float4*)(st_img + ((size_t)oy * W + ox) * 256 + cot * 64 + n * 16 + 4 * kg) =
+                            make_float4(r[n][0], r[n][1], r[n][2], r[n][3]);
+                    acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                if (sp_img && ok) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float f8[8] = {r[2 * j][0], r[2 * j][1], r[2 * j][2], r[2 * j][3],
+                                             r[2 * j + 1][0], r[2 * j + 1][1], r[2 * j + 1][2], r[2 * j + 1][3]};
+                        u32x4 hi, lo;
+                        split8_sp(f8, hi, lo);
+                        const int cig = cot * 8 + j * 4 + kg;
+                        *(u32x4*)(sp_img + sp_offset(cig, 0, oy, ox, H, W)) = hi;
+                        *(u32x4*)(sp_img + sp_offset(cig, 1, oy, ox, H, W)) = lo;
+                    }
+                }
+            }
+            asm volatile("" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+#undef ISSUE_A1
+#undef ISSUE_W1
+#if VST_SP_ABLATE & 8
+    // diagnostic build only: shader cycles and 100 MHz ticks of one mid-grid workgroup overwrite the head of the output planes
+    if (blockIdx.x == gridDim.x / 2 && tid == 0 && !OUT_STATE) {
+        unsigned long long* d = (unsigned long long*)a.out_sp;
+        d[0] = __builtin_amdgcn_s_memtime() - stamp_t0;
+        d[1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+    }
+#endif
+}
+
+// fp32 state half (ZC, level 2: [y][x][256]) -> its SP shadow.  One wave = 64 consecutive x of one 8-channel group.
+__global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__ state, unsigned char* __restrict__ sp,
+                                                      int B, int H, int W) {
+    const size_t total = (size_t)B * 32 * H * W;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = idx % W;
+        size_t rest = idx / W;
+        const int y = rest % H; rest /= H;
+        const int cig = rest % 32;
+        const int b = rest / 32;
+        const int cot = cig >> 3, j = (cig >> 2) & 1, kg = cig & 3;
+        const float* p = state + (((size_t)b * H + y) * W + x) * 256 + cot * 64 + j * 32 + kg * 4;
+        const float4 v0 = *(const float4*)p, v1 = *(const float4*)(p + 16);
+        const float f8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        u32x4 hi, lo;
+        split8_sp(f8, hi, lo);
+        unsigned char* o = sp + (size_t)b * 1024 * H * W;
+        *(u32x4*)(o + sp_offset(cig, 0, y, x, H, W)) = hi;
+        *(u32x4*)(o + sp_offset(cig, 1, y, x, H, W)) = lo;
+    }
+}
+
+template <int CIN, int COUT, bool OUT_STATE>
+static int launch_sp(SpArgs a, int B, hipStream_t st) {
+    using C = SpCfg<CIN, COUT>;
+    auto kern = conv_sp_kernel<CIN, COUT, OUT_STATE>;
+    static std::atomic<unsigned> attr_done{0};
+    if (int rc = vst_ensure_dynamic_lds((const void*)kern, C::LDS_BYTES, &attr_done)) return rc;
+    a.tiles_x = (a.W + 15) / 16; a.tiles_y = (a.H + C::TH - 1) / C::TH; a.tiles_total = a.tiles_x * a.tiles_y * B;
+    vst_prof_scope prof(VST_KERNEL_ID(CIN, COUT, 1), st);
+    kern<<<dim3((a.tiles_total + 7) / 8 * 8), 64 * C::NW, C::LDS_BYTES, st>>>(a);
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
+int vst3_block256(const vst_block_weights* w, int direction, int precision, float* dst, const float* src, void* tmp,
+                  int shadow_valid, int write_shadow, int B, int H, int W, void* stream) {
+    if (precision != VST_PREC_F16X2) return VST_E_MODE;
+    hipStream_t st = (hipStream_t)stream;
+    const int Hq = H >> 2, Wq = W >> 2;
+    const size_t mid_bytes = (size_t)Hq * Wq * 64 * 4, state_bytes = (size_t)Hq * Wq * 256 * 4;
+    unsigned char* h1 = (unsigned char*)tmp;
+    unsigned char* h2 = h1 + (size_t)B * mid_bytes;
+    unsigned char* shadow = h2 + (size_t)B * mid_bytes;
+    if (!shadow_valid) {
+        const size_t total = (size_t)B * 32 * Hq * Wq;
+        size_t blocks = (total + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        presplit_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(src, shadow, B, Hq, Wq);
+        VST_RETURN_IF_LAUNCH_FAILED();
+    }
+    SpArgs a{};
+    a.H = Hq; a.W = Wq; a.state_img_floats = (size_t)Hq * Wq * 256;
+    auto frag = [](const vst_conv_weights& c, int cout, int cin) {
+        const PackedConvLayout L = packed_conv_layout(cout, cin);
+        return (const unsigned char*)c.packed + L.f32_bytes + 2 * L.frag_bytes;
+    };
+    // conv.1: shadow(src) -> h1
+    a.in = shadow; a.in_img_bytes = state_bytes; a.out_sp = h1; a.out_img_bytes = mid_bytes; a.state = nullptr;
+    a.wfrag = frag(w->conv[0], 64, 256); a.bias = w->conv[0].bias; a.sign = 0.f;
+    int rc = launch_sp<256, 64, false>(a, B, st);
+    if (rc) return rc;
+    // conv.4: h1 -> h2
+    a.in = h1; a.in_img_bytes = mid_bytes; a.out_sp = h2;
+    a.wfrag = frag(w->conv[1], 64, 64); a.bias = w->conv[1].bias;
+    rc = launch_sp<64, 64, false>(a, B, st);
+    if (rc) return rc;
+    // conv.7: h2 -> dst += sign * (.), shadow(dst) for the next block's conv.1
+    a.in = h2; a.out_sp = write_shadow ? shadow : nullptr; a.out_img_bytes = state_bytes; a.state = dst;
+    a.wfrag = frag(w->conv[2], 256, 64); a.bias = w->conv[2].bias;
+    a.sign = direction > 0 ? 1.f : -1.f;
+    return launch_sp<64, 256, true>(a, B, st);
+}

@@ -743,7 +743,7 @@ static int launch_apply_split(const float* x, float* y, long L, const float* aff
     if (wgs > 2048) wgs = 2048;
     const size_t lds = (size_t)2 * MB * KS * 64 * 16 + N * sizeof(float);
     auto kern = cwct_apply_split_kernel<N>;
-    static unsigned attr_done = 0;
+    static std::atomic<unsigned> attr_done{0};
     if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)lds, &attr_done)) return rc_;
     kern<<<dim3((unsigned)wgs), 256, lds, st>>>(x, y, L, affine, niter);
     VST_RETURN_IF_LAUNCH_FAILED();
@@ -759,7 +759,7 @@ static int launch_apply_mfma(const float* x, float* y, long L, const float* affi
     if (wgs > 2048) wgs = 2048;
     const size_t lds = ((size_t)N * (N + 1) + N) * sizeof(float);
     auto kern = cwct_apply_mfma_kernel<NBLK, PXV>;
-    static unsigned attr_done = 0;
+    static std::atomic<unsigned> attr_done{0};
     if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)((int)lds), &attr_done)) return rc_;
     kern<<<dim3((unsigned)wgs), 256, lds, st>>>(x, y, L, affine, mask, label, ngroups);
     VST_RETURN_IF_LAUNCH_FAILED();
@@ -845,7 +845,7 @@ int vst_cwct_factor(const double* content_stats, const double* const* style_stat
     a.n_styles = n_styles; a.alpha_c = alpha_c; a.eps = eps; a.N = N; a.affine = affine; a.info = info;
     const size_t lds = (size_t)N * N * 4 + (size_t)3 * N * 4 + 16;
     hipStream_t st = (hipStream_t)stream;
-    static unsigned attr_done = 0;
+    static std::atomic<unsigned> attr_done{0};
     if (int rc_ = vst_ensure_dynamic_lds((const void*)cwct_factor_kernel<8>, (int)(80 * 1024), &attr_done)) return rc_;
     switch (N) {
         case 16: cwct_factor_kernel<1><<<1, 256, lds, st>>>(a); break;

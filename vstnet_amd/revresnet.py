@@ -18,7 +18,7 @@ import torch.nn as nn
 from . import _lib
 from .synth import STACK, CONV_IDX
 
-_PRECISIONS = {"bf16x3": _lib.PREC_BF16X3, "fp32": _lib.PREC_FP32}
+_PRECISIONS = {"bf16x3": _lib.PREC_BF16X3, "fp32": _lib.PREC_FP32, "f16x2": _lib.PREC_F16X2}
 
 
 def _stream_ptr() -> C.c_void_p:
