@@ -9,11 +9,17 @@ only for the barrier and the max-over-ranks clock.  Inputs are resident in HBM b
 
     python bench.py [--gpus N --steps K --warmup W] [--size 1024] [--mode photo|art]
                     [--frames-per-gpu 1] [--recompute-style] [--no-cpu-baseline]
+
+`python bench.py --gpus N` (N > 1) without a launcher starts its own N ranks (one child process per rank,
+before this process touches a GPU); under `python -m torch.distributed.run --nproc-per-node N` it uses the
+ranks it is given.  Rank 0 prints the one JSON line.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,10 +27,19 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
+MFMA_16BIT_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak
+
+# conv kernel classes by profile id (cin, cout, stride) -> (stage, output-pixel divisor w.r.t. the full-resolution frame,
+# multiply-accumulates per output pixel and launch); the (4,16) and (16,64) ids are the fused conv.4 + conv.7 launches
+CONV_CLASSES = {
+    (16, 4, 1): ("stage1", 1, 16 * 4), (4, 16, 1): ("stage1", 1, 4 * 4 + 4 * 16),
+    (16, 16, 2): ("stage2", 4, 16 * 16), (64, 16, 1): ("stage2", 4, 64 * 16), (16, 64, 1): ("stage2", 4, 16 * 16 + 16 * 64),
+    (64, 64, 2): ("stage3", 16, 64 * 64), (256, 64, 1): ("stage3", 16, 256 * 64), (64, 64, 1): ("stage3", 16, 64 * 64),
+    (64, 256, 1): ("stage3", 16, 64 * 256),
+}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -33,33 +48,75 @@ def main():
     ap.add_argument("--height", type=int, default=None, help="frame height if not square (e.g. 1080 with --width 1920)")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--masked", type=int, default=0, help="K > 0: per-region cWCT with K-label synthetic masks (config 5)")
+    ap.add_argument("--mask-kind", default="bands", choices=["bands", "noise"], help="synthetic label maps: vertical bands, or "
+                    "per-pixel random labels (the worst case for any per-label tile skipping)")
     ap.add_argument("--mode", default="photo", choices=["photo", "art"])
     ap.add_argument("--frames-per-gpu", type=int, default=1)
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32"])
+    ap.add_argument("--precision", default="f16x2", choices=["f16x2", "bf16x3", "fp32"])
     ap.add_argument("--recompute-style", action="store_true", help="re-encode + re-factor the style every frame "
                     "(the reference's video loop, video_transfer.py:195) instead of caching it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the per-stage table and the recompute-style rate")
     ap.add_argument("--inplace-cwct", action="store_true", help="overwrite the content code with the transferred code")
     ap.add_argument("--host-pipeline", type=int, default=0, metavar="FRAMES", help="also time FRAMES uint8 frames that "
                     "start and end in host memory through vstnet_amd.pipeline.FramePipeline (PCIe-inclusive rate; "
                     "reported as an extra field, never as `value`)")
     ap.add_argument("--streams", type=int, default=2, help="independent frames in flight per GPU, one HIP stream each "
                     "(the MFMA-bound and the HBM-bound kernels of different frames overlap); 1 = strictly sequential")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run-ms", type=float, default=0.0, help="host-logic rehearsal (tests): no GPU work, a step sleeps "
+                    "this many milliseconds; exercises launch, rendezvous, timing and the JSON line only")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(n, argv):
+    """Start one child per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment) and wait for all of
+    them.  The parent never initialises a GPU; a failed rank takes the others down and its exit code is returned."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in pending:      # exactly the children started above
+                    other.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def main():
+    args = parse_args()
+    # decide on self-launch before anything touches the GPU (the children do; this process never does)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
+    from vstnet_amd.sharding import dist_env, shard_range, timed_steps
+    rank, local_rank, world = dist_env()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}")
+    if args.dry_run_ms > 0:
+        return dry_run(args, rank, world)
+
     from models.RevResNet import RevResNet
     from models.cWCT import cWCT
     from vstnet_amd import _lib
     from vstnet_amd.synth import synthetic_state_dict, synthetic_frames
-
-    from vstnet_amd.sharding import dist_env, shard_range, timed_steps
-    rank, local_rank, world = dist_env()
-    n_dev = torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()          # counting devices does not initialise HIP
     use_nccl = world <= n_dev                 # fewer GPUs than ranks (rehearsal on a 1-GPU box): ranks share GPUs, gloo
-    if args.gpus > 1 or world > 1:
-        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank % n_dev)
         if use_nccl:
@@ -93,8 +150,8 @@ def main():
     if args.masked:
         from vstnet_amd.synth import synthetic_mask
         assert args.mode == "photo", "this fork's masked cWCT needs masks at code resolution (photorealistic codes)"
-        cmask = np.stack([synthetic_mask(Hf, Wf, args.masked, seed=3)] * fpg)
-        smask = np.stack([synthetic_mask(Hf, Wf, args.masked, seed=4, speck=False)] * fpg)
+        cmask = np.stack([synthetic_mask(Hf, Wf, args.masked, seed=3, kind=args.mask_kind)] * fpg)
+        smask = np.stack([synthetic_mask(Hf, Wf, args.masked, seed=4, speck=False, kind=args.mask_kind)] * fpg)
 
     with torch.no_grad():
         z_s = net(style)
@@ -104,19 +161,22 @@ def main():
             plan = cw.bind_style(cw.plan_masks(cmask, smask, (fpg,) + tuple(z_s.shape[1:]), (fpg,) + tuple(z_s.shape[1:]), dev),
                                  z_s.expand(fpg, -1, -1, -1))
 
-        def stylize_batch():
+        def stylize_batch(recompute=args.recompute_style, keep=None):
             z_c = net(content, forward=True)
-            if args.masked and plan is not None:
+            if args.masked and plan is not None and not recompute:
                 z_cs = cw.transfer_with_plan(z_c, None, plan)
             elif args.masked:
                 zs = net(style, forward=True)
                 z_cs = cw.transfer(z_c, zs.expand(fpg, -1, -1, -1), cmask, smask)
-            elif args.recompute_style:
+            elif recompute:
                 zs = net(style, forward=True)
                 z_cs = cw.transfer(z_c, zs.expand(fpg, -1, -1, -1))
             else:
-                z_cs = cw.transfer_with_stats(z_c, s_stats, inplace=args.inplace_cwct)
-            return net(z_cs, forward=False)
+                z_cs = cw.transfer_with_stats(z_c, s_stats, inplace=args.inplace_cwct and keep is None)
+            out = net(z_cs, forward=False)
+            if keep is not None:
+                keep.update(z_c=z_c, z_cs=z_cs, stylized=out)
+            return out
 
         # every step is one independent batch; consecutive steps alternate over `--streams` HIP streams so that
         # up to that many frames are in flight (all inputs / style statistics are ready before the timed region)
@@ -124,37 +184,42 @@ def main():
         torch.cuda.synchronize()
         counter = [0]
 
-        def step():
+        def step(**kw):
             st = streams[counter[0] % len(streams)]
             counter[0] += 1
             with torch.cuda.stream(st):
-                return stylize_batch()
+                return stylize_batch(**kw)
 
-        elapsed = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, world, device=dev if use_nccl else "cpu")
+        elapsed, per_rank_s = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, world,
+                                          device=dev if use_nccl else "cpu", return_all=True)
         assert torch.isfinite(step()).all()
+        torch.cuda.synchronize()
 
-        # ---- live roofline of the dominant kernel: HIP events around each of its launches ------------
-        L = _lib.lib()
-        cin, cout = 256, 64                         # stage-3 / channel_reduction conv.1 (largest share of MFMA work)
-        _lib.check(L.vst_profile_begin(_lib.kernel_id(cin, cout, 1), 4096), "vst_profile_begin")
-        for _ in range(max(1, min(args.steps, 10))):     # one frame at a time on one stream: with frames in flight on two
-            with torch.cuda.stream(streams[0]):          # streams the events would also time the other frame's kernels
-                stylize_batch()
-            streams[0].synchronize()
-        tot_ms, n_launch = C.c_double(0), C.c_int(0)
-        _lib.check(L.vst_profile_end(C.byref(tot_ms), C.byref(n_launch)), "vst_profile_end")
-        avg_ms = tot_ms.value / max(1, n_launch.value)
-        px = fpg * (Hf // 4) * (Wf // 4)
-        alg_flops = 2.0 * 9 * cin * cout * px        # fp32-equivalent conv flops (the split executes 3x as bf16 MFMA)
-        achieved_tf = alg_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-
-    # HBM bytes per launch of that kernel from the committed PMC summary (separate rocprofv3 --pmc passes of this same
-    # command; FETCH_SIZE corrected x2 for gfx950) — only valid for the workload it was taken on
-    traffic = None
-    pmc_path = os.path.join(REPO, "profiles", "r01_pmc_hbm_traffic.json")
-    if os.path.exists(pmc_path) and (Hf, Wf) == (1024, 1024) and fpg == 1 and args.mode == "photo":
-        k = json.load(open(pmc_path))["kernels"].get(f"void conv_pipe_kernel<{cin}, {cout}, true, false>(ConvArgs)")
-        traffic = k["hbm_bytes_per_launch"] if k else None
+        # ---- extras, all outside the timed region ----------------------------------------------------------------------
+        extras = {}
+        table = {}
+        n_prof = max(1, min(args.steps, 5))
+        if rank == 0:
+            # HIP events around every launch, one frame at a time on one stream (with frames in flight on two streams the
+            # events would also time the other frame's kernels)
+            def prof_frames():
+                for _ in range(n_prof):
+                    with torch.cuda.stream(streams[0]):
+                        stylize_batch()
+                    streams[0].synchronize()
+            table = _lib.profile_table(prof_frames)
+        if rank == 0 and not args.no_extras and not args.masked:
+            t3 = timed_steps(lambda: step(recompute=True), max(2, min(args.steps, 10)), 2, torch.cuda.synchronize, 1)
+            n3 = max(2, min(args.steps, 10))
+            extras["recompute_style"] = {
+                "value": round(fpg * n3 / t3, 3), "unit": "frames/s", "per": "GPU", "passes": 3,
+                "note": "style re-encoded and re-factored for every frame (the reference's video loop, video_transfer.py:195): "
+                        "3 RevResNet passes + style statistics per frame"}
+        gpu_out = {}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.masked:
+            stylize_batch(recompute=False, keep=gpu_out)
+            torch.cuda.synchronize()
+            gpu_out = {k: v[:1].float().cpu() for k, v in gpu_out.items()}
 
     frames_total = world * fpg * args.steps
     ms_per_step = elapsed / args.steps * 1e3
@@ -162,26 +227,27 @@ def main():
     passes = 3 if args.recompute_style else 2
     frame_bytes = (passes * 6540 + 384) * Hf * Wf + (128 * Hf * Wf if args.recompute_style else 0)
     frame_gbs = frame_bytes * fpg * args.steps / elapsed / 1e9     # per GPU
+    per_rank_fps = [round(fpg * args.steps / t, 3) for t in per_rank_s]
 
+    prec_note = {"f16x2": "f32 state / f32 accumulate; fp16 2-term split MFMA in the 256-channel blocks, bf16 3-term split MFMA elsewhere",
+                 "bf16x3": "f32 state / f32 accumulate; bf16 3-term split MFMA", "fp32": "f32"}[args.precision]
     rec = {
         "metric": "stylized frames/sec at 1024x1024 (1/2/4/8 GPU) + % HBM roofline",
         "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (bf16x3 split MFMA, f32 accumulate/state)" if args.precision == "bf16x3" else "f32",
-        "data": "synthetic",
+        "dtype": prec_note, "data": "synthetic",
         "config": {"workload": f"{'photorealistic' if args.mode == 'photo' else 'artistic'} {Wf}x{Hf} frame: RevResNet "
-                   f"forward + cWCT ({str(args.masked) + '-label masked, ' if args.masked else ''}{'style re-encoded per frame' if args.recompute_style else 'style statistics cached'})"
+                   f"forward + cWCT ({str(args.masked) + '-label ' + args.mask_kind + ' masks, ' if args.masked else ''}{'style re-encoded per frame' if args.recompute_style else 'style statistics cached'})"
                    " + RevResNet inverse", "frames_per_gpu": fpg, "sharding": f"{world} ranks x {fpg} frame(s), no collective",
-                   "weights": "synthetic seed 1234", "frames_in_flight": max(1, args.streams)},
-        "roofline": {"kernel": f"conv_pipe_kernel<{cin},{cout}> (stage-3 / channel_reduction conv.1)", "bound": "mfma",
-                     "achieved": round(achieved_tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved_tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
-                     "avg_launch_ms": round(avg_ms, 5), "launches_timed": n_launch.value,
-                     "note": "achieved counts algorithmic fp32 conv flops; the bf16x3 split issues 3x that on the MFMA pipe"},
+                   "weights": "synthetic seed 1234", "frames_in_flight": max(1, args.streams), "precision": args.precision},
+        "per_rank": {"frames_per_s": per_rank_fps, "min": min(per_rank_fps), "max": max(per_rank_fps)},
         "frame_hbm_roofline": {"bound": "hbm", "algorithmic_bytes_per_frame": frame_bytes,
                                "achieved": round(frame_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(frame_gbs / HBM_PEAK_GBS, 4), "per": "GPU"},
     }
+    if rank == 0 and table:
+        rec["roofline"], rec["stages"] = roofline_from_table(table, n_prof, fpg, Hf, Wf, args, _lib)
+    rec.update(extras)
 
     if args.host_pipeline > 0 and not args.masked and fpg == 1:
         # PCIe-inclusive: uint8 frames in pageable host memory -> pinned ring -> H2D -> encode/cWCT/decode -> D2H -> host
@@ -199,7 +265,89 @@ def main():
                                 "frames": args.host_pipeline, "note": "uint8 HWC frames from and to host memory, pinned "
                                 "ring buffers, H2D/compute/D2H overlapped; PCIe-inclusive, not `value`"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        rec["cpu_baseline"] = cpu_baseline(sd, sp, Hf, Wf)
+        rec["cpu_baseline"] = cpu_baseline(sd, sp, Hf, Wf, gpu_out)
+    if rank == 0:
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def roofline_from_table(table, n_frames, fpg, H, W, args, _lib):
+    """Per-launch roofline of the conv class with the largest total time, and a per-stage summary, from the HIP-event
+    table of `n_frames` frames run one at a time (ms are per frame below)."""
+    px = fpg * H * W                                   # full-resolution pixels per frame batch
+    f16 = args.precision == "f16x2"
+    per = {}                                           # (cin, cout, stride) -> (ms per frame, launches per frame)
+    for kid, (ms, cnt) in table.items():
+        if kid >= 65536:
+            per[(kid >> 16, (kid >> 4) & 0xFFF, kid & 15)] = (ms / n_frames, cnt / n_frames)
+    # ---- dominant conv class -------------------------------------------------------------------------------------------
+    per = {k: v for k, v in per.items() if k in CONV_CLASSES}
+    (cin, cout, stride), (ms, cnt) = max(per.items(), key=lambda kv: kv[1][0])
+    _, div, macs = CONV_CLASSES[(cin, cout, stride)]
+    flops = 2.0 * 9 * macs * px / div                  # fp32-equivalent conv flops of one launch
+    avg_ms = ms / cnt
+    terms = 2 if (f16 and cin >= 64 and cout >= 64 and stride == 1) else 3
+    achieved = flops / (avg_ms * 1e-3) / 1e12
+    kname = (f"conv_sp_kernel<{cin},{cout}> (fp16 2-term, LDS-DMA)" if terms == 2 else f"conv kernel <{cin},{cout},s{stride}> (bf16 3-term)")
+    traffic = None
+    pmc_path = os.path.join(REPO, "profiles", "r02_pmc_hbm_traffic.json")
+    if os.path.exists(pmc_path) and (H, W) == (1024, 1024) and fpg == 1 and args.mode == "photo" and f16:
+        k = json.load(open(pmc_path))["kernels"]
+        hit = [v for n, v in k.items() if f"<{cin}, {cout}," in n and "conv_sp" in n]
+        traffic = hit[0]["hbm_bytes_per_launch"] if hit else None
+    roof = {"kernel": kname + " — the conv class with the largest total time per frame", "bound": "mfma",
+            "achieved": round(achieved, 2), "peak": MFMA_16BIT_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_16BIT_PEAK_TFLOPS, 4), "traffic": traffic,
+            "avg_launch_ms": round(avg_ms, 5), "launches_per_frame": round(cnt, 1), "ms_per_frame": round(ms, 4),
+            "issued_frac": round(achieved * terms / MFMA_16BIT_PEAK_TFLOPS, 4),
+            "note": f"achieved counts algorithmic fp32 conv flops (2*9*cin*cout per output pixel of the launch); the split issues {terms}x that on the "
+                    "MFMA pipe (issued_frac); HIP events on the launch stream, one frame at a time"}
+    # ---- per-stage summary ------------------------------------------------------------------------------------------------
+    stage_ms = {"stage1": 0.0, "stage2": 0.0, "stage3": 0.0, "cwct": 0.0, "glue": 0.0}
+    stage_issued = {"stage1": 0.0, "stage2": 0.0, "stage3": 0.0}
+    for (ci, co, st_), (m, c) in per.items():
+        stg, dv, mc = CONV_CLASSES[(ci, co, st_)]
+        stage_ms[stg] += m
+        t = 2 if (f16 and ci >= 64 and co >= 64 and st_ == 1) else 3
+        stage_issued[stg] += 2.0 * 9 * mc * px / dv * c * t
+    for kid, (m, c) in table.items():
+        if kid < 65536:
+            name = _lib.MISC_KERNELS.get(kid, "")
+            key = "cwct" if name.startswith("cwct") else ("stage3" if name == "presplit" else "glue")
+            stage_ms[key] += m / n_frames
+    # algorithmic bytes per frame (SURVEY 8(d)): 192 B per full-res pixel and block, 396 B glue per pass, 384 B cWCT
+    blocks = {"stage1": 10 + 10 - 1, "stage2": 20, "stage3": 24}          # forward block 0 is folded into the input packing
+    stage_bytes = {k: v * 192.0 * px for k, v in blocks.items()}
+    stage_bytes["glue"] = 2 * 396.0 * px
+    stage_bytes["cwct"] = 384.0 * px
+    stages = {}
+    for k, m in stage_ms.items():
+        stages[k] = {"ms_per_frame": round(m, 4), "algorithmic_TBps": round(stage_bytes[k] / (m * 1e-3) / 1e12, 3) if m > 0 else None}
+        if k in stage_issued:
+            stages[k]["issued_PFLOPps"] = round(stage_issued[k] / (m * 1e-3) / 1e15, 3) if m > 0 else None
+    stages["sum_ms_per_frame"] = round(sum(stage_ms.values()), 4)
+    stages["note"] = "HIP-event kernel time of one frame at a time (launch gaps included per launch); stage3 includes channel_reduction"
+    return roof, stages
+
+
+def dry_run(args, rank, world):
+    """No GPU: the launcher / rendezvous / timing / JSON path only (covered by tests/test_bench_launch.py)."""
+    import torch.distributed as dist
+    from vstnet_amd.sharding import timed_steps
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    fpg = args.frames_per_gpu
+    elapsed, per_rank_s = timed_steps(lambda: time.sleep(args.dry_run_ms * 1e-3), args.steps, args.warmup, lambda: None, world,
+                                      return_all=True)
+    per_rank_fps = [round(fpg * args.steps / t, 3) for t in per_rank_s]
+    rec = {"metric": "stylized frames/sec at 1024x1024 (1/2/4/8 GPU) + % HBM roofline", "value": round(world * fpg * args.steps / elapsed, 3),
+           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "none", "data": "dry-run (no GPU work; not a measurement)",
+           "config": {"workload": "dry run", "frames_per_gpu": fpg},
+           "per_rank": {"frames_per_s": per_rank_fps, "min": min(per_rank_fps), "max": max(per_rank_fps)}}
     if rank == 0:
         print(json.dumps(rec), flush=True)
     if world > 1:
@@ -219,27 +367,56 @@ def usable_cores():
     return max(1, min(n, int(os.environ.get("VST_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(sd, sp, H, W):
-    """The oracle (CPU restatement of the reference's torch-op sequence) timed on this host's cores on ONE
-    frame of the same workload (style code precomputed, like the GPU leg)."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sd, sp, H, W, gpu_out=None, timed_frames=3):
+    """The oracle (CPU restatement of the reference's torch-op sequence) timed on this host's cores: one warm-up frame, then
+    `timed_frames` frames of the same workload (style code precomputed, like the GPU leg).  The warm-up frame is the GPU
+    leg's frame 0, so its code / transferred code / stylised frame are also the parity check of the GPU outputs."""
     import torch
     from oracle import cpu_ref
     from vstnet_amd.synth import synthetic_frames
     cores = usable_cores()
     torch.set_num_threads(cores)
-    xc, xs = synthetic_frames(1, H, W, seed=0), synthetic_frames(1, H, W, seed=1)
+    xs = synthetic_frames(1, H, W, seed=1)
+    xc = synthetic_frames(1 + timed_frames, H, W, seed=0)      # frame f = seed (0, f), as in the GPU leg
     with torch.no_grad():
-        small = synthetic_frames(1, 64, 64, seed=2)
-        cpu_ref.revnet_inverse(cpu_ref.revnet_forward(small, sd, sp), sd, sp)       # warm the thread pool
         zs = cpu_ref.revnet_forward(xs, sd, sp)
-        t0 = time.perf_counter()
-        zc = cpu_ref.revnet_forward(xc, sd, sp)
-        zcs = cpu_ref.transfer(zc, zs)
-        cpu_ref.revnet_inverse(zcs, sd, sp)
-        dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 frame {W}x{H} (forward + cWCT + inverse, style code precomputed), oracle/cpu_ref.py on torch CPU ops",
-            "seconds": round(dt, 2)}
+
+        def frame(i):
+            zc = cpu_ref.revnet_forward(xc[i:i + 1], sd, sp)
+            zcs = cpu_ref.transfer(zc, zs)
+            return zc, zcs, cpu_ref.revnet_inverse(zcs, sd, sp)
+        ref = frame(0)                                          # warm-up (thread pool, allocator) + parity reference
+        times = []
+        for i in range(1, 1 + timed_frames):
+            t0 = time.perf_counter()
+            frame(i)
+            times.append(time.perf_counter() - t0)
+    dt = sum(times) / len(times)
+    rec = {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "threads": torch.get_num_threads(),
+           "cpu_model": cpu_model(), "host_cores_visible": os.cpu_count(), "kind": "port",
+           "sample": f"1 warm-up + {timed_frames} timed frames {W}x{H} (forward + cWCT + inverse, style code precomputed), "
+                     "oracle/cpu_ref.py on torch CPU ops", "seconds_per_frame": [round(t, 2) for t in times]}
+    if gpu_out:
+        par = {}
+        for name, r in zip(("z_c", "z_cs", "stylized"), ref):
+            g = gpu_out[name].double()
+            r = r.double()
+            par[name] = {"rel_l2": float(((g - r).norm() / r.norm())), "max_rel": float(((g - r).abs().max() / r.abs().max()))}
+        rec["parity_rel_l2"] = max(v["rel_l2"] for v in par.values())
+        rec["parity_max_rel"] = max(v["max_rel"] for v in par.values())
+        rec["parity"] = {k: {a: float(f"{b:.3e}") for a, b in v.items()} for k, v in par.items()}
+        rec["parity_note"] = "GPU frame 0 of this run vs the oracle on the same inputs and weights; budget 1e-3 (north_star)"
+    return rec
 
 
 if __name__ == "__main__":

@@ -158,8 +158,20 @@ int vst_cwct_prefactor(const double* stats, int N, float eps, double* out, int* 
  *   vst_profile_end(&total_ms, &launches)   (synchronises on the recorded events)
  * ------------------------------------------------------------------------------------------- */
 #define VST_KERNEL_ID(cin, cout, stride) (((cin) << 16) | ((cout) << 4) | (stride))
+#define VST_KERNEL_ALL (-1)        /* every hooked launch; read the session with vst_profile_end_table */
+/* ids of the non-conv launches (one per C entry point) */
+#define VST_KERNEL_PACK 1          /* vst_pack_input* (+ the folded block-0 constant) */
+#define VST_KERNEL_UNPACK 2
+#define VST_KERNEL_SPREAD 3
+#define VST_KERNEL_GATHER 4
+#define VST_KERNEL_CWCT_STATS 5
+#define VST_KERNEL_CWCT_FACTOR 6
+#define VST_KERNEL_CWCT_APPLY 7
+#define VST_KERNEL_PRESPLIT 8      /* fp32 state -> split fp16 planes in front of the first 256-channel block (F16X2) */
 int vst_profile_begin(int kernel_id, int max_records);
 int vst_profile_end(double* total_ms, int* launches);
+/* per-id totals of a VST_KERNEL_ALL (or single-id) session: ids[i], ms[i], launches[i] for i < *n_ids <= cap */
+int vst_profile_end_table(int* ids, double* ms, int* launches, int cap, int* n_ids);
 
 #ifdef __cplusplus
 }

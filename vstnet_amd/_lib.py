@@ -28,7 +28,7 @@ EXPORTS = [
     "vst_spread", "vst_gather", "vst_block_tmp_bytes", "vst_block_apply",
     "vst_pass_workspace_bytes", "vst_revnet_forward", "vst_revnet_inverse",
     "vst_cwct_stats_workspace_bytes", "vst_cwct_stats", "vst_cwct_factor", "vst_cwct_apply",
-    "vst_cwct_prefactor", "vst_profile_begin", "vst_profile_end", "vst_lab_luminance",
+    "vst_cwct_prefactor", "vst_profile_begin", "vst_profile_end", "vst_profile_end_table", "vst_lab_luminance",
 ]
 
 
@@ -117,6 +117,7 @@ def lib() -> C.CDLL:
         "vst_cwct_prefactor": (i, [vp, i, f, vp, vp, vp]),
         "vst_profile_begin": (i, [i, i]),
         "vst_profile_end": (i, [C.POINTER(C.c_double), C.POINTER(i)]),
+        "vst_profile_end_table": (i, [C.POINTER(i), C.POINTER(C.c_double), C.POINTER(i), i, C.POINTER(i)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -124,6 +125,23 @@ def lib() -> C.CDLL:
         fn.argtypes = args
     _lib = L
     return L
+
+
+KERNEL_ALL = -1
+MISC_KERNELS = {1: "pack_input", 2: "unpack_output", 3: "spread", 4: "gather", 5: "cwct_stats", 6: "cwct_factor",
+                7: "cwct_apply", 8: "presplit"}
+
+
+def profile_table(run, max_records: int = 4096):
+    """HIP-event time of every hooked launch that ``run()`` makes: {kernel id: (total ms, launches)}."""
+    L = lib()
+    check(L.vst_profile_begin(KERNEL_ALL, max_records), "vst_profile_begin")
+    try:
+        run()
+    finally:
+        ids, ms, cnt, n = (C.c_int * 64)(), (C.c_double * 64)(), (C.c_int * 64)(), C.c_int(0)
+        check(L.vst_profile_end_table(ids, ms, cnt, 64, C.byref(n)), "vst_profile_end_table")
+    return {ids[k]: (ms[k], cnt[k]) for k in range(n.value)}
 
 
 def kernel_id(cin: int, cout: int, stride: int) -> int:

@@ -844,14 +844,17 @@ __global__ __launch_bounds__(256) void conv_fp32_kernel(const ConvArgs a, int CI
 static std::mutex g_prof_mu;
 static std::atomic<int> g_prof_kernel{0};   // 0 = off, else VST_KERNEL_ID(cin, cout, stride)
 static int g_prof_count = 0, g_prof_cap = 0;
+static int g_prof_id[VST_PROFILE_MAX_RECORDS];
 static hipEvent_t g_prof_ev[2 * VST_PROFILE_MAX_RECORDS];
 static bool g_prof_ev_created = false;
 
 int vst_prof_open(int kernel_id, hipStream_t st) {
-    if (g_prof_kernel.load(std::memory_order_relaxed) != kernel_id) return -1;     // the common case: no lock taken
+    const int sel = g_prof_kernel.load(std::memory_order_relaxed);
+    if (sel != kernel_id && sel != VST_KERNEL_ALL) return -1;                       // the common case: no lock taken
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (g_prof_kernel.load() != kernel_id || g_prof_count >= g_prof_cap) return -1;
+    if ((g_prof_kernel.load() != kernel_id && g_prof_kernel.load() != VST_KERNEL_ALL) || g_prof_count >= g_prof_cap) return -1;
     const int rec = g_prof_count++;
+    g_prof_id[rec] = kernel_id;
     (void)hipEventRecord(g_prof_ev[2 * rec], st);
     return rec;
 }
@@ -961,7 +964,7 @@ static const int kBlockStride[VST_NUM_BLOCKS] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2
 extern "C" {
 
 int vst_profile_begin(int kernel_id, int max_records) {
-    if (kernel_id <= 0 || max_records <= 0) return VST_E_ARG;
+    if ((kernel_id <= 0 && kernel_id != VST_KERNEL_ALL) || max_records <= 0) return VST_E_ARG;
     if (max_records > VST_PROFILE_MAX_RECORDS) max_records = VST_PROFILE_MAX_RECORDS;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof_ev_created) {
@@ -995,6 +998,30 @@ int vst_profile_end(double* total_ms, int* launches) {
 }
 
 // h1 + h2 (8 floats per pixel) + the split-plane shadow of one state half for the stage-3 kernels of conv3.hip (16)
+int vst_profile_end_table(int* ids, double* ms, int* launches, int cap, int* n_ids) {
+    if (!ids || !ms || !launches || !n_ids || cap <= 0) return VST_E_ARG;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_kernel.store(0);
+    int n = 0;
+    for (int i = 0; i < g_prof_count; ++i) {
+        hipError_t e = hipEventSynchronize(g_prof_ev[2 * i + 1]);
+        if (e != hipSuccess) return (int)e;
+        float t = 0.f;
+        e = hipEventElapsedTime(&t, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]);
+        if (e != hipSuccess) return (int)e;
+        int k = 0;
+        while (k < n && ids[k] != g_prof_id[i]) ++k;
+        if (k == n) {
+            if (n == cap) continue;
+            ids[n] = g_prof_id[i]; ms[n] = 0.0; launches[n] = 0; ++n;
+        }
+        ms[k] += t; launches[k] += 1;
+    }
+    *n_ids = n;
+    g_prof_count = 0; g_prof_cap = 0;
+    return VST_OK;
+}
+
 size_t vst_block_tmp_bytes(int B, int H, int W) { return (size_t)B * H * W * 24 * sizeof(float); }
 
 int vst_block_apply(const vst_block_weights* w, int channel, int stride, int direction, int precision,

@@ -329,6 +329,7 @@ int vst3_block256(const vst_block_weights* w, int direction, int precision, floa
         const size_t total = (size_t)B * 32 * Hq * Wq;
         size_t blocks = (total + 255) / 256;
         if (blocks > 16384) blocks = 16384;
+        vst_prof_scope prof(VST_KERNEL_PRESPLIT, st);
         presplit_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(src, shadow, B, Hq, Wq);
         VST_RETURN_IF_LAUNCH_FAILED();
     }

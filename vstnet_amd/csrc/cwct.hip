@@ -809,6 +809,7 @@ int vst_cwct_stats(const float* x, int N, long L, const uint8_t* mask, int label
     const int G = cwct_stats_groups(L, &per);
     float* partial = (float*)workspace;
     const bool vec = (L % 4) == 0 && ((uintptr_t)x % 16) == 0 && (mask == nullptr || ((uintptr_t)mask % 4) == 0);
+    vst_prof_scope prof(VST_KERNEL_CWCT_STATS, st);
     switch (N) {
         case 16: cwct_stats_partial_kernel<1><<<G, 256, 0, st>>>(x, L, mask, label, partial, per); break;
         case 32: if (vec) cwct_stats_mfma_kernel<1, true><<<G, 256, 0, st>>>(x, L, mask, label, partial, per);
@@ -847,6 +848,7 @@ int vst_cwct_factor(const double* content_stats, const double* const* style_stat
     hipStream_t st = (hipStream_t)stream;
     static std::atomic<unsigned> attr_done{0};
     if (int rc_ = vst_ensure_dynamic_lds((const void*)cwct_factor_kernel<8>, (int)(80 * 1024), &attr_done)) return rc_;
+    vst_prof_scope prof(VST_KERNEL_CWCT_FACTOR, st);
     switch (N) {
         case 16: cwct_factor_kernel<1><<<1, 256, lds, st>>>(a); break;
         case 32: cwct_factor_kernel<2><<<1, 256, lds, st>>>(a); break;
@@ -875,6 +877,7 @@ int vst_cwct_apply(const float* x, float* y, int N, long L, const float* affine,
                    void* stream) {
     if (!x || !y || !affine || L <= 0) return VST_E_ARG;
     hipStream_t st = (hipStream_t)stream;
+    vst_prof_scope prof(VST_KERNEL_CWCT_APPLY, st);
     switch (N) {
         case 16: return launch_apply<16>(x, y, L, affine, mask, label, st);
         case 32: return launch_apply<32>(x, y, L, affine, mask, label, st);

@@ -274,6 +274,7 @@ int vst_pack_input_k(const float* x, const uint8_t* x_u8, float* s1, float* s2, 
     hipError_t e = hipMemsetAsync(s2, 0, (size_t)B * H * W * 16 * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
     const dim3 grid((W + 63) / 64, (H + 3) / 4, B);
+    vst_prof_scope prof(VST_KERNEL_PACK, st);
     if (x_u8) pack_input_u8_kernel<<<grid, 256, 0, st>>>(x_u8, s1, H, W, addk);
     else pack_input_kernel<<<grid, 256, 0, st>>>(x, s1, C, H, W, addk);
     VST_RETURN_IF_LAUNCH_FAILED();
@@ -296,6 +297,7 @@ int vst_pack_input(const float* x, float* s1, float* s2, int B, int C, int H, in
 int vst_unpack_output(const float* s1, float* x, int B, int C, int H, int W, void* stream) {
     if (!x || !s1) return VST_E_ARG;
     if (!vst_shape_ok(B, H, W) || C < 1 || C > 16) return VST_E_SHAPE;
+    vst_prof_scope prof(VST_KERNEL_UNPACK, (hipStream_t)stream);
     unpack_output_kernel<<<dim3((W + 63) / 64, (H + 3) / 4, B), 256, 0, (hipStream_t)stream>>>(s1, x, C, H, W);
     VST_RETURN_IF_LAUNCH_FAILED();
     return VST_OK;
@@ -309,6 +311,7 @@ int vst_pack_input_u8(const uint8_t* frames_hwc, float* s1, float* s2, int B, in
 int vst_unpack_output_u8(const float* s1, uint8_t* frames_hwc, int B, int H, int W, void* stream) {
     if (!frames_hwc || !s1) return VST_E_ARG;
     if (!vst_shape_ok(B, H, W)) return VST_E_SHAPE;
+    vst_prof_scope prof(VST_KERNEL_UNPACK, (hipStream_t)stream);
     unpack_output_u8_kernel<<<dim3((W + 63) / 64, (H + 3) / 4, B), 256, 0, (hipStream_t)stream>>>(s1, frames_hwc, H, W);
     VST_RETURN_IF_LAUNCH_FAILED();
     return VST_OK;
@@ -319,6 +322,7 @@ int vst_spread(const float* s1, const float* s2, float* z, int B, int H, int W, 
     if (!vst_shape_ok(B, H, W)) return VST_E_SHAPE;
     const dim3 grid((W / 4 + 15) / 16, H / 4, B);
     hipStream_t st = (hipStream_t)stream;
+    vst_prof_scope prof(VST_KERNEL_SPREAD, st);
     if (sp_steps == 2) spread_gather_kernel<2, true><<<grid, 256, 0, st>>>((float*)s1, (float*)s2, z, H, W);
     else if (sp_steps == 1) spread_gather_kernel<1, true><<<grid, 256, 0, st>>>((float*)s1, (float*)s2, z, H, W);
     else return VST_E_MODE;
@@ -331,6 +335,7 @@ int vst_gather(const float* z, float* s1, float* s2, int B, int H, int W, int sp
     if (!vst_shape_ok(B, H, W)) return VST_E_SHAPE;
     const dim3 grid((W / 4 + 15) / 16, H / 4, B);
     hipStream_t st = (hipStream_t)stream;
+    vst_prof_scope prof(VST_KERNEL_GATHER, st);
     if (sp_steps == 2) spread_gather_kernel<2, false><<<grid, 256, 0, st>>>(s1, s2, (float*)z, H, W);
     else if (sp_steps == 1) spread_gather_kernel<1, false><<<grid, 256, 0, st>>>(s1, s2, (float*)z, H, W);
     else return VST_E_MODE;

@@ -26,9 +26,10 @@ def dist_env():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def timed_steps(step, steps: int, warmup: int, sync, world: int, device=None):
+def timed_steps(step, steps: int, warmup: int, sync, world: int, device=None, return_all: bool = False):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + sync on both sides;
-    returns the MAX over ranks of the elapsed seconds (the bench contract)."""
+    returns the MAX over ranks of the elapsed seconds (the bench contract) — with ``return_all`` also every
+    rank's own time between its two syncs (for the per-rank report)."""
     import torch
     import torch.distributed as dist
     for _ in range(warmup):
@@ -40,11 +41,18 @@ def timed_steps(step, steps: int, warmup: int, sync, world: int, device=None):
     for _ in range(steps):
         step()
     sync()
+    own = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    every = [own]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device or "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    return elapsed
+        if return_all:
+            mine = torch.tensor([own], dtype=torch.float64, device=device or "cpu")
+            gathered = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(gathered, mine)
+            every = [float(g.item()) for g in gathered]
+    return (elapsed, every) if return_all else elapsed

@@ -65,10 +65,19 @@ def synthetic_frames(batch: int, height: int, width: int, seed: int = 0) -> torc
     return torch.from_numpy(np.stack(frames))
 
 
-def synthetic_mask(height: int, width: int, labels: int = 5, seed: int = 0, speck: bool = True) -> np.ndarray:
-    """uint8 [H,W] label map: vertical bands of `labels` labels (+ one <=10-px speck of label `labels`
-    that exercises the validity rule of models/cWCT.py:178)."""
+def synthetic_mask(height: int, width: int, labels: int = 5, seed: int = 0, speck: bool = True,
+                   kind: str = "bands") -> np.ndarray:
+    """uint8 [H,W] label map (+ one <=10-px speck of label `labels` that exercises the validity rule of
+    models/cWCT.py:178).  kind "bands": vertical bands of `labels` labels; kind "noise": an independent uniform
+    label per pixel — every 64-pixel tile holds every label, the worst case for per-label passes."""
     rng = np.random.Generator(np.random.PCG64([seed, 77]))
+    if kind == "noise":
+        m = rng.integers(0, labels, size=(height, width), dtype=np.uint8)
+        if speck:
+            m[1:3, 1:4] = labels
+        return m
+    if kind != "bands":
+        raise ValueError("kind must be 'bands' or 'noise'")
     cuts = np.sort(rng.choice(np.arange(8, width - 8), size=labels - 1, replace=False))
     m = np.zeros((height, width), dtype=np.uint8)
     for i, c in enumerate(cuts):
