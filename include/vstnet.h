@@ -133,7 +133,11 @@ int vst_revnet_inverse_u8(const vst_net_weights* w, const float* z, uint8_t* fra
  *                   Lc = chol(Cc), Ls_i = chol(Cs_i) with the cumulative-jitter retry of
  *                   cholesky_dec (cWCT.py:111-132), mixL = sum_i alpha_i Ls_i (+ alpha_c blend,
  *                   cWCT.py:231-254), T = mixL * Lc^-1, t0 = mix_mean - T*mean_c.
- *                   affine = float[N*N + N] {T, t0};  info = int[2 + n_styles] retry counts.
+ *                   affine = float[N*N + N] {T, t0};  info = int[2 + n_styles], IN/OUT: on entry the minimum
+ *                   number of retries to start from (zeros normally; the reference factors a whole
+ *                   [B,N,N] batch at once, cWCT.py:122-128, so a failing sample jitters every sample: a
+ *                   caller reproduces that by a second call with the batch maximum), on exit
+ *                   {content retries, overflow flag, style retries...}.
  * vst_cwct_apply  : y[:,p] = T x[:,p] + t0  (cWCT.py:147,161-162 fused); with a mask only pixels
  *                   whose label matches are written (in place allowed: y may alias x).
  * ------------------------------------------------------------------------------------------- */

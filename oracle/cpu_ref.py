@@ -172,18 +172,10 @@ def coloring(whiten, style, eps=2e-5):
 
 
 def transfer(content, style, eps=2e-5, use_double=False):
-    """C-1: the INTENDED no-mask semantics of models/cWCT.py:24-47 — per-sample
-    coloring(whitening(c_b), s_b).  (The fork's batched `whitening` raises on 3-D input,
-    SURVEY.md 8(a) C-1; per-sample 2-D calls are what upstream computes and are bit-identical to
-    interpolation(c,[s],[1.0],0.0).)"""
-    B, N, H, W = content.shape
-    dt = content.dtype
-    c = content.reshape(B, N, -1)
-    s = style.reshape(B, N, -1)
-    if use_double:
-        c, s = c.double(), s.double()
-    out = torch.stack([coloring(whitening(c[b], eps), s[b], eps) for b in range(B)])
-    return out.to(dt).reshape(B, N, H, W)
+    """C-1: the INTENDED no-mask semantics of models/cWCT.py:24-47 (the fork's batched `whitening` raises on 3-D input,
+    SURVEY.md 8(a) C-1): coloring(whitening(c), s) on the whole [B,N,L] batch, which is what `interpolation(c, [s],
+    [1.0], 0.0)` computes (models/cWCT.py:206-262) — including its batch-wide Cholesky jitter (see `interpolation`)."""
+    return interpolation(content, [style], [1.0], 0.0, eps, use_double)
 
 
 # --------------------------------------------------------------------------- C-5 masked
@@ -230,8 +222,9 @@ def transfer_seg(content, style, cmask, smask, eps=2e-5, use_double=False):
 
 # --------------------------------------------------------------------------- C-6 interpolation
 def interpolation(content, styles, alphas, alpha_c=0.0, eps=2e-5, use_double=False):
-    """models/cWCT.py:206-262 — whiten content once, mix the styles' Cholesky factors and means,
-    optionally blend with the content's own factor/mean."""
+    """models/cWCT.py:206-262 — whiten content once, mix the styles' Cholesky factors and means, optionally blend with
+    the content's own factor/mean.  Everything is batched over B like the reference, so `cholesky_dec` sees the [B,N,N]
+    stack: if ANY sample's covariance fails, the jitter is added to EVERY sample's (models/cWCT.py:115-128)."""
     assert len(styles) == len(alphas)
     B, N, H, W = content.shape
     dt = content.dtype
@@ -240,28 +233,24 @@ def interpolation(content, styles, alphas, alpha_c=0.0, eps=2e-5, use_double=Fal
         c = c.double()
     cmean = c.mean(-1)
     cc = c - cmean.unsqueeze(-1)
-    out = torch.empty_like(cc)
-    for b in range(B):
-        conv = (cc[b] @ cc[b].t()) / (cc.shape[-1] - 1)
-        invLc = cholesky_dec(conv, eps, invert=True)
-        whiten = invLc @ cc[b]
-        mixL = torch.zeros_like(invLc)
-        mixm = torch.zeros_like(cmean[b])
-        for sf, a in zip(styles, alphas):
-            assert sf.shape[0] == B and sf.shape[1] == N
-            s = sf.reshape(B, N, -1)[b]
-            if use_double:
-                s = s.double()
-            sm = s.mean(-1)
-            sc = s - sm.unsqueeze(-1)
-            sconv = (sc @ sc.t()) / (s.shape[-1] - 1)
-            mixL = mixL + cholesky_dec(sconv, eps) * a
-            mixm = mixm + sm * a
-        if alpha_c != 0.0:
-            Lc = cholesky_dec(conv, eps)
-            mixL = mixL * (1 - alpha_c) + Lc * alpha_c
-            mixm = mixm * (1 - alpha_c) + cmean[b] * alpha_c
-        out[b] = mixL @ whiten + mixm.unsqueeze(-1)
+    conv = (cc @ cc.transpose(-1, -2)) / (cc.shape[-1] - 1)
+    whiten = cholesky_dec(conv, eps, invert=True) @ cc
+    mixL = torch.zeros_like(conv)
+    mixm = torch.zeros_like(cmean)
+    for sf, a in zip(styles, alphas):
+        assert sf.shape[0] == B and sf.shape[1] == N
+        s = sf.reshape(B, N, -1)
+        if use_double:
+            s = s.double()
+        sm = s.mean(-1)
+        sc = s - sm.unsqueeze(-1)
+        sconv = (sc @ sc.transpose(-1, -2)) / (s.shape[-1] - 1)
+        mixL = mixL + cholesky_dec(sconv, eps) * a
+        mixm = mixm + sm * a
+    if alpha_c != 0.0:
+        mixL = mixL * (1 - alpha_c) + cholesky_dec(conv, eps) * alpha_c
+        mixm = mixm * (1 - alpha_c) + cmean * alpha_c
+    out = mixL @ whiten + mixm.unsqueeze(-1)
     return out.to(dt).reshape(B, N, H, W)
 
 

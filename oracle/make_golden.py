@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import io
 import contextlib
+import importlib.util
 import os
 import sys
 import types
@@ -240,9 +241,54 @@ def main():
     save("cwct_jitter", conv=conv, L=Lr, tries=tries, ones4_L=Ls_ref, ones4_tries=t2,
          neg_in=neg, neg_L=Ln_ref, neg_tries=t3)
 
+    # C-4 x C-6: the jitter couples the samples of a batch.  Sample 0 has a constant channel (zero variance: the pivot is
+    # exactly 0 in any arithmetic -> the batched Cholesky fails once), sample 1 is ordinary; the reference then adds eps*I
+    # to BOTH covariances (models/cWCT.py:122-128).
+    cj = torch.stack([rnd((32, 8, 8), 950), rnd((32, 8, 8), 951) * 1.5 + 0.2])
+    cj[0, 31] = 0.25
+    sj = torch.stack([rnd((32, 6, 10), 952) * 0.7, rnd((32, 6, 10), 953) - 0.3])
+    gj = {}
+    for ac in (0.0, 0.3):
+        o = cw.interpolation(cj, [sj], [1.0], ac)
+        check(f"batch-coupled jitter alpha_c={ac}", cpu_ref.interpolation(cj, [sj], [1.0], ac), o, 2e-5)
+        gj[f"out_ac{ac}"] = o
+    cjc = cj.reshape(2, 32, -1) - cj.reshape(2, 32, -1).mean(-1, keepdim=True)
+    _, tj = cpu_ref.cholesky_dec(cjc @ cjc.transpose(-1, -2) / 63, return_tries=True)
+    print(f"  batch-coupled jitter: retries for the [2,32,32] content stack = {tj}")
+    save("cwct_batch_jitter", c=cj, s=sj, tries=tj, **gj)
+
+    # ------------------------------------------------------------------ mask producers (8(f) rank 3)
+    print("segremap")
+    spec = importlib.util.spec_from_file_location("reference_segremap", os.path.join(REF, "models", "segmentation", "SegReMapping.py"))
+    segmod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(segmod)
+    table_path = os.path.join(REF, "models", "segmentation", "ade20k_semantic_rel.npy")
+    ref_map = segmod.SegReMapping(table_path)
+    from models.segmentation.SegReMapping import SegReMapping as OurMap
+    ours_map, loop_map = OurMap(table_path), cpu_ref.SegReMappingLoop(np.load(table_path))
+    rng = np.random.Generator(np.random.PCG64([77, 1]))
+    gs = {"mapping": np.load(table_path).astype(np.int16)}
+    for t in range(6):
+        K = int(rng.integers(4, 12))
+        labs = rng.choice(150, size=K, replace=False)
+        seg = labs[rng.choice(K, size=(48, 64), p=rng.dirichlet(np.full(K, 0.4)))].astype(np.uint8)
+        seg[0, :4] = int(rng.integers(0, 150))              # a 4-pixel region (< min_ratio) -> remapped
+        seg[10:12, 20:23] = int(rng.integers(0, 150))
+        sty_labs = np.concatenate([labs[: K // 2], rng.choice(150, size=3, replace=False)])   # half the labels are absent
+        sty = sty_labs[rng.integers(0, len(sty_labs), size=(40, 40))].astype(np.uint8)
+        a = ref_map.self_remapping(seg)
+        b = ref_map.self_remapping(sty)
+        c_ = ref_map.cross_remapping(a, b)
+        for impl, nm in ((ours_map, "models/segmentation/SegReMapping"), (loop_map, "cpu_ref.SegReMappingLoop")):
+            assert np.array_equal(impl.self_remapping(seg), a) and np.array_equal(impl.self_remapping(sty), b), (nm, t)
+            assert np.array_equal(impl.cross_remapping(a, b), c_), (nm, t)
+        print(f"  [ok] case {t}: {len(np.unique(seg))} -> {len(np.unique(a))} -> {len(np.unique(c_))} content labels; "
+              f"style {len(np.unique(sty))} -> {len(np.unique(b))}")
+        gs.update({f"seg_{t}": seg, f"sty_{t}": sty, f"self_seg_{t}": a, f"self_sty_{t}": b, f"cross_{t}": c_})
+    save("segremap", n_cases=6, min_ratio=0.01, **gs)
+
     # ------------------------------------------------------------------ Lab luminance post-process (fork's project/ package)
     print("lab")
-    import importlib.util
     spec = importlib.util.spec_from_file_location("reference_color", os.path.join(REF, "project", "image_style", "color.py"))
     color = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(color)

@@ -456,8 +456,9 @@ def test_input_forms_and_sample():
     assert not xt.is_contiguous()
     assert torch.equal(net(xt.cuda()), base)
     assert_close(net(x.double().cuda()), base, 1e-7, "fp64 input")
-    cw = cWCT(use_double=True)
-    out = cw.transfer(base.double(), base.double().flip(-1))
+    with pytest.raises(NotImplementedError):
+        cWCT(use_double=True)                        # no fp64 Cholesky / apply in the HIP path: rejected, not ignored
+    out = cWCT().transfer(base.double(), base.double().flip(-1))
     assert out.dtype == torch.float64 and out.shape == base.shape
     xc, xs, xcs, cyc = net.sample(cWCT(), x, synthetic_frames(1, 32, 32, seed=52), "cuda")
     assert xcs.shape == x.shape and cyc.shape == x.shape and torch.isfinite(xcs).all()
@@ -652,6 +653,85 @@ def test_full_size_config5_1080p_masked():
         assert float((_cov(a) - _cov(b)).abs().max() / _cov(b).abs().max()) < 2e-4, label
     speck = cmt == 5
     assert int(speck.sum()) == 6 and torch.equal(a_all[:, speck], c_all[:, speck])
+
+
+# ------------------------------------------------------------------------------------------- full size vs the oracle itself
+_FULL = {}
+
+
+def _oracle_1024(mode):
+    """cpu_ref.stylize once per mode at 1024x1024 (config 2 / one frame of config 3): ~6 s on the box's 16 cores."""
+    if mode not in _FULL:
+        hd, sp = (16, 2) if mode == "photo" else (64, 1)
+        sd = synthetic_state_dict(1234, hd, sp)
+        torch.set_num_threads(16)
+        xc, xs = synthetic_frames(1, 1024, 1024, seed=0), synthetic_frames(1, 1024, 1024, seed=1)
+        with torch.no_grad():
+            _FULL[mode] = (xc, xs) + tuple(cpu_ref.stylize(xc, xs, sd, sp))
+    return _FULL[mode]
+
+
+@pytest.mark.parametrize("precision,tol", [("f16x2", 2e-4), ("bf16x3", TIGHT)])
+@pytest.mark.parametrize("mode", ["photo", "art"])
+def test_full_size_1024_vs_oracle(mode, precision, tol):
+    """BASELINE config 2 (photo) and a config-3 frame (art) at the full 1024x1024 against the oracle on the same inputs:
+    rel-L2 and max-rel of z_c, z_cs and the stylised frame (north_star budget 1e-3; the asserted bounds are tighter)."""
+    from models.cWCT import cWCT
+    xc, xs, zc, zs, zcs, sty = _oracle_1024(mode)
+    net, _, _ = make_net(mode, precision)
+    cw = cWCT()
+    with torch.no_grad():
+        g_zc, g_zs = net(xc.cuda()), net(xs.cuda())
+        g_zcs = cw.transfer(g_zc, g_zs)
+        g_sty = net(g_zcs, forward=False)
+    assert_close(g_zc, zc, tol, f"{mode}/{precision} z_c")
+    assert_close(g_zcs, zcs, tol, f"{mode}/{precision} z_cs", tol_max=max(tol, 2e-4))
+    assert_close(g_sty, sty, tol, f"{mode}/{precision} stylized")
+    assert tol <= TOL
+
+
+def test_batch_coupled_jitter_golden(golden):
+    """the reference factors the [B,N,N] stack at once: sample 0's singular covariance jitters sample 1 too (cWCT.py:122-128)"""
+    from models.cWCT import cWCT
+    g = golden("cwct_batch_jitter")
+    cw = cWCT()
+    c, s = T(g["c"]).cuda(), T(g["s"]).cuda()
+    for ac in (0.0, 0.3):
+        out = cw.interpolation(c, [s], [1.0], ac)
+        # sample 0 has a zero-variance channel: its whitening is ill-conditioned by construction (1/sqrt(eps) gain)
+        assert_close(out[1], T(g[f"out_ac{ac}"])[1], 2e-5, f"coupled sample, alpha_c={ac}", tol_max=1e-4)
+        assert_close(out[0], T(g[f"out_ac{ac}"])[0], 2e-3, f"singular sample, alpha_c={ac}", tol_max=2e-2)
+    assert cw.last_info.cpu().tolist()[0] == int(g["tries"]) == 1
+    # per-sample (uncoupled) factoring of sample 1 differs measurably: the coupling is what the golden pins
+    alone = cw.interpolation(c[1:2], [s[1:2]], [1.0], 0.0)
+    assert rel_err(alone[0], T(g["out_ac0.0"])[1])[0] > 1e-5
+
+
+def test_art_mode_inplace_and_masked_128():
+    """N = 128 paths with thin coverage so far: the in-place split-operand apply (y == x) and the masked apply on a
+    >= 2000-pixel region, pointwise against the oracle"""
+    from models.cWCT import cWCT
+    net, sd, sp = make_net("art")
+    cw = cWCT(resize_masks=True)
+    H, W = 192, 256                                   # code 96 x 128 = 12288 pixels (L % 64 == 0: split-operand kernel)
+    xc, xs = synthetic_frames(1, H, W, seed=71), synthetic_frames(1, H, W, seed=72)
+    with torch.no_grad():
+        zc_o, zs_o = cpu_ref.revnet_forward(xc, sd, sp), cpu_ref.revnet_forward(xs, sd, sp)
+        ref = cpu_ref.transfer(zc_o, zs_o)
+        zc, zs = net(xc.cuda()), net(xs.cuda())
+        stats = cw.style_stats(zs)
+        out = cw.transfer_with_stats(zc, stats)
+        assert_close(out, ref, 2e-4, "art transfer (N=128)", tol_max=TOL)
+        keep = zc.clone()
+        same = cw.transfer_with_stats(zc, stats, inplace=True)
+        assert same.data_ptr() == zc.data_ptr() and torch.equal(same, out) and not torch.equal(zc, keep)
+        # masked: two labels of ~6000 code pixels each (>> 128 channels: well conditioned), masks at image resolution
+        cm = np.zeros((1, H, W), np.uint8); cm[:, :, W // 2:] = 1
+        sm = np.zeros((1, H, W), np.uint8); sm[:, H // 2:, :] = 1
+        cmr, smr = cw.resize(cm[0], H // 2, W // 2)[None], cw.resize(sm[0], H // 2, W // 2)[None]
+        refm = cpu_ref.transfer_seg(zc_o, zs_o, cmr, smr)
+        gotm = cw.transfer(keep, zs, cm, sm)
+        assert_close(gotm, refm, 2e-4, "masked art z_cs, 6144-pixel regions", tol_max=TOL)
 
 
 def test_network_vs_oracle_seeded_shapes():

@@ -34,10 +34,13 @@ def test_header_symbols_exported(lib):
 
 def test_sizes_and_errors_without_gpu(lib):
     assert lib.vst_version() >= 100
-    assert lib.vst_pass_workspace_bytes(1, 1024, 1024) == 1024 * 1024 * 160
-    assert lib.vst_block_tmp_bytes(2, 64, 32) == 2 * 64 * 32 * 32
-    # packed conv = fp32 taps-major + 2 x bf16 fragment sections
-    assert lib.vst_conv_packed_bytes(64, 256) == 9 * 256 * 64 * 4 + 2 * (72 * 4 * 64 * 16)
+    # two state halves (64 B/px each) + h1/h2 (32 B/px) + the split-plane shadow of one half for the F16X2 kernels (64 B/px)
+    assert lib.vst_pass_workspace_bytes(1, 1024, 1024) == 1024 * 1024 * 224
+    assert lib.vst_block_tmp_bytes(2, 64, 32) == 2 * 64 * 32 * 96
+    # packed conv = fp32 taps-major + 2 x bf16 fragment sections (+ 1 fp16 section in the LDS-DMA kernels' K order for the
+    # 256-channel blocks' shapes)
+    assert lib.vst_conv_packed_bytes(64, 256) == 9 * 256 * 64 * 4 + 3 * (72 * 4 * 64 * 16)
+    assert lib.vst_conv_packed_bytes(64, 16) == 9 * 16 * 64 * 4 + 2 * (5 * 4 * 64 * 16)
     assert lib.vst_conv_packed_bytes(4, 16) == ((9 * 16 * 4 * 4 + 255) // 256 * 256) + 2 * (5 * 4 * 16 * 16)
     assert lib.vst_cwct_stats_workspace_bytes(32, 1 << 20) == 512 * (32 * 32 + 64 + 4) * 4
     # argument validation happens before any launch

@@ -112,6 +112,33 @@ def test_cholesky_jitter(golden):
     close(L2, T(g["neg_L"]), 1e-5)
 
 
+def test_batch_coupled_jitter(golden):
+    """[B,N,N] stacks are factored at once: one failing sample jitters the whole batch (models/cWCT.py:122-128)"""
+    g = golden("cwct_batch_jitter")
+    c, s = T(g["c"]), T(g["s"])
+    for ac in (0.0, 0.3):
+        close(cpu_ref.interpolation(c, [s], [1.0], ac), T(g[f"out_ac{ac}"]), 2e-5)
+    close(cpu_ref.transfer(c, s), T(g["out_ac0.0"]), 2e-5)
+    cc = c.reshape(2, 32, -1) - c.reshape(2, 32, -1).mean(-1, keepdim=True)
+    _, tries = cpu_ref.cholesky_dec(cc @ cc.transpose(-1, -2) / 63, return_tries=True)
+    assert tries == int(g["tries"]) == 1
+
+
+def test_segremap_golden(golden):
+    """mask producers (8(f) rank 3) against outputs of the reference's own SegReMapping on its real ADE20K relation table:
+    the drop-in (histogram + LUT) and the oracle's loop restatement"""
+    from models.segmentation.SegReMapping import SegReMapping
+    g = golden("segremap")
+    table = g["mapping"].astype(np.int64)
+    assert table.shape == (150, 150) and np.array_equal(table[-1], np.arange(150))
+    for impl in (SegReMapping(table, float(g["min_ratio"])), cpu_ref.SegReMappingLoop(table, float(g["min_ratio"]))):
+        for t in range(int(g["n_cases"])):
+            a = impl.self_remapping(g[f"seg_{t}"])
+            b = impl.self_remapping(g[f"sty_{t}"])
+            assert a.dtype == np.uint8 and np.array_equal(a, g[f"self_seg_{t}"]) and np.array_equal(b, g[f"self_sty_{t}"])
+            assert np.array_equal(impl.cross_remapping(a, b), g[f"cross_{t}"])
+
+
 def test_config1(golden):
     g = golden("config1_photo256")
     sd = synthetic_state_dict(int(g["weights_seed"]))

@@ -404,10 +404,11 @@ __device__ bool fac_chol(float (&r)[BLK][BLK], int ti, int tj, float* col, float
 }
 
 // lower Cholesky factor of the covariance in `stats` (or the stored factor if the record is prefactored:
-// stats[0] < 0) -> r; returns the number of jitter retries
+// stats[0] < 0) -> r; returns the number of jitter retries.  min_tries > 0 starts the schedule there (the reference
+// factors a [B,N,N] stack at once, so a sample inherits the retries another sample of its batch needed)
 template <int BLK>
 __device__ int fac_factor(const double* stats, float eps, int ti, int tj, float (&r)[BLK][BLK], float* col, float* s_piv,
-                          int* s_flag) {
+                          int* s_flag, int min_tries = 0) {
     constexpr int N = 16 * BLK;
     if (stats[0] < 0.0) {
 #pragma unroll
@@ -416,7 +417,7 @@ __device__ int fac_factor(const double* stats, float eps, int ti, int tj, float 
             for (int b = 0; b < BLK; ++b) r[a][b] = (float)stats[1 + N + (ti + 16 * a) * N + tj + 16 * b];
         return 0;
     }
-    int tries = 0;
+    int tries = min_tries < 0 ? 0 : (min_tries > CWCT_MAX_TRIES ? CWCT_MAX_TRIES : min_tries);
     while (true) {
         fac_load<BLK>(stats, tries, eps, ti, tj, r);
         const bool failed = fac_chol<BLK>(r, ti, tj, col, s_piv, s_flag);
@@ -431,9 +432,8 @@ __global__ __launch_bounds__(256) void cwct_factor_kernel(const FactorArgs a) {
     constexpr int N = 16 * BLK;
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
     float* Lmat = (float*)fsm;             // N*N   Lc, row-major
-    float* col = Lmat + N * N;             // N     column broadcast of the Cholesky
-    float* tcol = col + N;                 // 2*N   column broadcast of the solve (double-buffered)
-    float* s_piv = tcol + 2 * N;
+    float* col = Lmat + N * N;             // 2*N   column broadcast of the Cholesky (look-ahead double buffer)
+    float* s_piv = col + 3 * N;            // (the launch reserves N*N + 3N floats + 16 bytes)
     int* s_flag = (int*)(s_piv + 1);
     const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
 
@@ -446,8 +446,8 @@ __global__ __launch_bounds__(256) void cwct_factor_kernel(const FactorArgs a) {
         for (int b = 0; b < BLK; ++b) m[a2][b] = 0.f;
     }
     for (int s = 0; s < a.n_styles; ++s) {
-        const int tries = fac_factor<BLK>(a.styles[s], a.eps, ti, tj, r, col, s_piv, s_flag);
-        if (tid == 0) a.info[2 + s] = tries;
+        const int tries = fac_factor<BLK>(a.styles[s], a.eps, ti, tj, r, col, s_piv, s_flag, a.info[2 + s]);
+        if (tid == 0) a.info[2 + s] = tries;      // (every thread read its minimum before the first barrier of fac_chol)
         const float al = a.alphas[s];
 #pragma unroll
         for (int a2 = 0; a2 < BLK; ++a2) {
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void cwct_factor_kernel(const FactorArgs a) {
             for (int b = 0; b < BLK; ++b) m[a2][b] += r[a2][b] * al;
         }
     }
-    const int ctries = fac_factor<BLK>(a.content, a.eps, ti, tj, r, col, s_piv, s_flag);
+    const int ctries = fac_factor<BLK>(a.content, a.eps, ti, tj, r, col, s_piv, s_flag, a.info[0]);
     if (tid == 0) { a.info[0] = ctries; a.info[1] = ctries >= CWCT_MAX_TRIES; }
     if (a.alpha_c != 0.f) {
         const float ac = a.alpha_c;

@@ -7,7 +7,11 @@ public-by-convention helpers).  Differences, all documented in DESIGN.md:
   * the Cholesky-failure path retries with the reference's jitter schedule but never enters pdb;
   * masks must have the feature resolution (the fork does not resize them, cWCT.py:72-73): a
     mismatch raises ValueError instead of indexing out of range;
-  * ``use_double`` only affects the dtype round trip: the statistics are always combined in fp64.
+  * ``use_double=True`` is rejected (NotImplementedError): the reference's scripts never set it (image_transfer.py:60,
+    video_transfer.py:63, train.py:94 all build ``cWCT()``; in this fork the flag traps into pdb, cWCT.py:36) and the HIP
+    path has no fp64 Cholesky / apply.  What it does in fp64 regardless: the mean / covariance combine;
+  * a batch is factored like the reference's [B,N,N] stack: a sample that needs Cholesky jitter jitters every sample
+    (cWCT.py:122-128); ``transfer_with_stats`` / ``transfer_with_plan`` (this repo's cached-style extensions) are per sample.
 All device work goes through libvstnet_hip.so; there is no CPU fallback.
 """
 from __future__ import annotations
@@ -44,8 +48,11 @@ class cWCT(nn.Module):
 
     def __init__(self, eps=2e-5, use_double=False, resize_masks=False):
         super().__init__()
+        if use_double:
+            raise NotImplementedError("vstnet_amd.cWCT(use_double=True): the HIP path factors and applies in fp32 (statistics "
+                                      "are combined in fp64); an fp64 Cholesky / apply is not implemented")
         self.eps = eps
-        self.use_double = use_double
+        self.use_double = False
         # upstream CAP-VSTNet resized the label maps to the feature resolution (NEAREST, cWCT.py:191-197); this
         # fork uses them as they are (:72-73), which only fits photorealistic codes.  Opt in to restore it.
         self.resize_masks = resize_masks
@@ -83,13 +90,14 @@ class cWCT(nn.Module):
                        "vst_cwct_stats")
         return out
 
-    def factor(self, content_stats, style_stats_list, alphas, alpha_c, N):
-        """{T, t0} with T = (sum_i a_i chol(Cs_i) [blended with chol(Cc)]) * chol(Cc)^-1."""
+    def factor(self, content_stats, style_stats_list, alphas, alpha_c, N, min_tries=None):
+        """{T, t0} with T = (sum_i a_i chol(Cs_i) [blended with chol(Cc)]) * chol(Cc)^-1.  min_tries: device int32
+        [2+n_styles] jitter retries to start from (the batch coupling of `interpolation`)."""
         L = _lib.lib()
         n = len(style_stats_list)
         dev = content_stats.device
         affine = torch.empty(N * N + N, dtype=torch.float32, device=dev)
-        info = torch.zeros(2 + n, dtype=torch.int32, device=dev)
+        info = torch.zeros(2 + n, dtype=torch.int32, device=dev) if min_tries is None else min_tries.clone()
         ptrs = (C.c_void_p * n)(*[s.data_ptr() for s in style_stats_list])
         al = (C.c_float * n)(*[float(a) for a in alphas])
         with torch.cuda.device(dev):
@@ -136,11 +144,19 @@ class cWCT(nn.Module):
             assert sf.shape[0] == B and sf.shape[1] == N
             styles.append(self._prep(sf).reshape(B, N, -1))
         out = torch.empty_like(c)
+        stats = [(self.stats(c[b]), [self.stats(s[b]) for s in styles]) for b in range(B)]
+        affines, infos = [], []
+        for cs, ss in stats:
+            affines.append(self.factor(cs, ss, alpha_s_list, alpha_c, N))
+            infos.append(self.last_info)
+        if B > 1:
+            # the reference factors the [B,N,N] stacks at once: if any sample needs jitter, every sample of the batch gets it
+            # (cWCT.py:122-128).  Second factor call from the batch maximum of the retry counts (on the device: no host sync).
+            need = torch.stack(infos).max(dim=0).values
+            need[1] = 0
+            affines = [self.factor(cs, ss, alpha_s_list, alpha_c, N, min_tries=need) for cs, ss in stats]
         for b in range(B):
-            cs = self.stats(c[b])
-            ss = [self.stats(s[b]) for s in styles]
-            affine = self.factor(cs, ss, alpha_s_list, alpha_c, N)
-            self.apply(c[b], affine, out=out[b])
+            self.apply(c[b], affines[b], out=out[b])
         return out.to(in_dtype).reshape(B, N, cH, cW)
 
     # ------------------------------------------------------------------ cached-style extension
