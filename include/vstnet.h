@@ -149,6 +149,11 @@ int vst_cwct_factor(const double* content_stats, const double* const* style_stat
                     float* affine, int* info, void* stream);
 int vst_cwct_apply(const float* x, float* y, int N, long L, const float* affine,
                    const uint8_t* mask, int label, void* stream);
+/* the same with the arithmetic chosen by the caller: VST_PREC_FP32 = exact-fp32 matrix-core / FMA kernels for every N,
+ * shape and mask; otherwise (the default of vst_cwct_apply) unmasked N >= 64 applies with L % 64 == 0 run on bf16 MFMA
+ * with split operands (3 products, ~1.5e-5 max-rel) and everything else is exact fp32 */
+int vst_cwct_apply_prec(const float* x, float* y, int N, long L, const float* affine,
+                        const uint8_t* mask, int label, int precision, void* stream);
 /* Turns a statistics record into a "prefactored" one ({-(n+1), mean, chol(cov) with jitter retries}); a style that
  * is reused over many frames (video_transfer.py re-factors it per frame, :195-203) then costs no Cholesky in
  * vst_cwct_factor.  `out` may alias `stats`; info = int[1] retry count. */

@@ -734,6 +734,31 @@ def test_art_mode_inplace_and_masked_128():
         assert_close(gotm, refm, 2e-4, "masked art z_cs, 6144-pixel regions", tol_max=TOL)
 
 
+def test_cwct_apply_precision_knob_ill_conditioned():
+    """N = 128, L % 64 == 0 (the split-operand bf16 apply) on a covariance of condition number ~1e4, where T = Ls Lc^-1 has
+    large cancelling entries: the split path must stay as close to the fp64 oracle as the exact-fp32 path does, and
+    precision='fp32' must select the exact kernels (the knob used to stop at RevResNet)."""
+    from models.cWCT import cWCT
+    N, Lp = 128, 64 * 64
+    g = torch.Generator().manual_seed(5)
+    q, _ = torch.linalg.qr(torch.randn(N, N, generator=g, dtype=torch.float64))
+    sv = torch.logspace(0, -2, N, dtype=torch.float64)            # singular values 1 .. 1e-2 -> cond(cov) = 1e4
+    c = (q @ (sv[:, None] * torch.randn(N, Lp, generator=g, dtype=torch.float64)) + 0.3).float().reshape(1, N, 64, 64)
+    s = (torch.randn(N, N, generator=g, dtype=torch.float64) @ torch.randn(N, Lp, generator=g, dtype=torch.float64) * 0.1).float()
+    s = s.reshape(1, N, 64, 64)
+    cc = c.reshape(N, -1).double()
+    cc = cc - cc.mean(-1, keepdim=True)
+    assert 5e3 < float(torch.linalg.cond(cc @ cc.t() / (Lp - 1))) < 5e4
+    ref = cpu_ref.transfer(c.double(), s.double())                # fp64 oracle
+    out_split = cWCT(precision="bf16x3").transfer(c.cuda(), s.cuda())
+    out_exact = cWCT(precision="fp32").transfer(c.cuda(), s.cuda())
+    e_split, e_exact = rel_err(out_split, ref), rel_err(out_exact, ref)
+    assert not torch.equal(out_split, out_exact)                  # the knob really switches kernels
+    assert e_exact[0] < 1e-3 and e_exact[1] < 1e-3, e_exact      # fp32 statistics + Cholesky at cond 1e4
+    assert e_split[0] <= max(2 * e_exact[0], 2e-4) and e_split[1] <= max(2 * e_exact[1], 5e-4), (e_split, e_exact)
+    assert_close(out_split, out_exact, 2e-4, "split vs exact apply", tol_max=5e-4)
+
+
 def test_network_vs_oracle_seeded_shapes():
     """a seeded sweep of odd frame shapes (tile edges in every position, batches, both modes) against the oracle"""
     rng = np.random.default_rng(2024)

@@ -149,3 +149,44 @@ def test_pipeline_host_helpers():
     if not __import__("torch").cuda.is_available():
         with pytest.raises(RuntimeError, match="needs the GPU"):
             FramePipeline(None, None, 64, 64)
+
+
+def test_prefetch_producer_stops_with_the_consumer():
+    """a consumer that stops early (exception / break) must not leave the decode thread blocked on a full queue"""
+    import threading
+    import time
+    from vstnet_amd.pipeline import prefetch
+    produced = []
+
+    def source():
+        for i in range(1000):
+            produced.append(i)
+            yield i
+
+    before = threading.active_count()
+    gen = prefetch(source(), ahead=2)
+    assert next(gen) == 0
+    gen.close()                                           # consumer goes away with the queue full
+    deadline = time.time() + 5
+    while threading.active_count() > before and time.time() < deadline:
+        time.sleep(0.05)
+    assert threading.active_count() <= before and len(produced) < 20
+    with pytest.raises(ZeroDivisionError):                # producer errors still reach the consumer
+        list(prefetch((1 // (3 - i) for i in range(5)), ahead=2))
+
+
+def test_packed_weights_follow_parameter_edits():
+    """the packed-weight cache is keyed on the parameters' versions: a parent module's load_state_dict or an in-place edit
+    repacks (no GPU here: only the cache key is checked)"""
+    import torch
+    from models.RevResNet import RevResNet
+    net = RevResNet()
+    convs = [blk.conv[ci] for blk in net._blocks() for ci in (1, 4, 7)]
+    v0 = net._param_versions(convs)
+    with torch.no_grad():
+        net.stack[3].conv[4].bias.add_(1.0)
+    v1 = net._param_versions(convs)
+    assert v0 != v1
+    holder = torch.nn.Sequential(net)
+    holder.load_state_dict(holder.state_dict())           # recurses without calling net.load_state_dict
+    assert net._param_versions(convs) != v1 and net._packed is None

@@ -138,7 +138,11 @@ def main(argv=None):
 
         def source():        # decode + resize in a background thread (img_resize: utils/utils.py:90-101)
             for i in range(lo, hi):
-                yield np.asarray(img_resize(frames[i], args.max_size, down_scale=net.down_scale), dtype=np.uint8)
+                arr = np.asarray(img_resize(frames[i], args.max_size, down_scale=net.down_scale), dtype=np.uint8)
+                if arr.shape[:2] != (ch_, cw_):     # the pinned ring, the mask plan and the writer are sized once per clip
+                    raise ValueError(f"frame {i} resizes to {arr.shape[1]}x{arr.shape[0]}, the clip's first frame to "
+                                     f"{cw_}x{ch_}: frames of one clip must share a size")
+                yield arr
 
         pipe = FramePipeline(net, transform, ch_, cw_, device=device, depth=args.depth, compute_streams=args.streams,
                              decode=decode, out_height=video_height, out_width=video_width)
@@ -146,7 +150,12 @@ def main(argv=None):
         try:
             pipe.run(prefetch(source(), ahead=args.depth), sink, start_index=lo)
         finally:
-            sink.close()
+            try:
+                sink.close()
+            finally:
+                if writer is not None:
+                    writer.release()
+                    writer = None
     if writer is not None:
         writer.release()
     print("Save stylized video at %s" % (frame_dir or args.out_dir))

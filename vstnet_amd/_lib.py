@@ -27,7 +27,7 @@ EXPORTS = [
     "vst_unpack_output", "vst_pack_input_u8", "vst_unpack_output_u8", "vst_revnet_forward_u8", "vst_revnet_inverse_u8",
     "vst_spread", "vst_gather", "vst_block_tmp_bytes", "vst_block_apply",
     "vst_pass_workspace_bytes", "vst_revnet_forward", "vst_revnet_inverse",
-    "vst_cwct_stats_workspace_bytes", "vst_cwct_stats", "vst_cwct_factor", "vst_cwct_apply",
+    "vst_cwct_stats_workspace_bytes", "vst_cwct_stats", "vst_cwct_factor", "vst_cwct_apply", "vst_cwct_apply_prec",
     "vst_cwct_prefactor", "vst_profile_begin", "vst_profile_end", "vst_profile_end_table", "vst_lab_luminance",
 ]
 
@@ -114,6 +114,7 @@ def lib() -> C.CDLL:
         "vst_cwct_stats": (i, [vp, i, lg, vp, i, vp, vp, vp]),
         "vst_cwct_factor": (i, [vp, C.POINTER(vp), C.POINTER(f), i, f, f, i, vp, vp, vp]),
         "vst_cwct_apply": (i, [vp, vp, i, lg, vp, vp, i, vp]),
+        "vst_cwct_apply_prec": (i, [vp, vp, i, lg, vp, vp, i, i, vp]),
         "vst_cwct_prefactor": (i, [vp, i, f, vp, vp, vp]),
         "vst_profile_begin": (i, [i, i]),
         "vst_profile_end": (i, [C.POINTER(C.c_double), C.POINTER(i)]),

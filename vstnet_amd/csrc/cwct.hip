@@ -771,8 +771,8 @@ static int launch_apply_mfma(const float* x, float* y, long L, const float* affi
 #endif
 template <int N>
 static int launch_apply(const float* x, float* y, long L, const float* affine, const uint8_t* mask, int label,
-                        hipStream_t st) {
-    if (N >= VST_APPLY_SPLIT_MIN_N && mask == nullptr && (L % 64) == 0 && (((uintptr_t)x | (uintptr_t)y) % 16) == 0)
+                        bool exact, hipStream_t st) {
+    if (!exact && N >= VST_APPLY_SPLIT_MIN_N && mask == nullptr && (L % 64) == 0 && (((uintptr_t)x | (uintptr_t)y) % 16) == 0)
         return launch_apply_split<(N >= 32 ? N : 32)>(x, y, L, affine, st);
     if (N >= 32) {                                           // matrix-core path (needs vector-aligned rows)
         constexpr int PXM = N == 32 ? 4 : 2;
@@ -873,18 +873,25 @@ int vst_cwct_prefactor(const double* stats, int N, float eps, double* out, int* 
     return VST_OK;
 }
 
-int vst_cwct_apply(const float* x, float* y, int N, long L, const float* affine, const uint8_t* mask, int label,
-                   void* stream) {
+int vst_cwct_apply_prec(const float* x, float* y, int N, long L, const float* affine, const uint8_t* mask, int label,
+                        int precision, void* stream) {
     if (!x || !y || !affine || L <= 0) return VST_E_ARG;
+    if (precision != VST_PREC_BF16X3 && precision != VST_PREC_FP32 && precision != VST_PREC_F16X2) return VST_E_MODE;
+    const bool exact = precision == VST_PREC_FP32;
     hipStream_t st = (hipStream_t)stream;
     vst_prof_scope prof(VST_KERNEL_CWCT_APPLY, st);
     switch (N) {
-        case 16: return launch_apply<16>(x, y, L, affine, mask, label, st);
-        case 32: return launch_apply<32>(x, y, L, affine, mask, label, st);
-        case 64: return launch_apply<64>(x, y, L, affine, mask, label, st);
-        case 128: return launch_apply<128>(x, y, L, affine, mask, label, st);
+        case 16: return launch_apply<16>(x, y, L, affine, mask, label, exact, st);
+        case 32: return launch_apply<32>(x, y, L, affine, mask, label, exact, st);
+        case 64: return launch_apply<64>(x, y, L, affine, mask, label, exact, st);
+        case 128: return launch_apply<128>(x, y, L, affine, mask, label, exact, st);
         default: return VST_E_SHAPE;
     }
+}
+
+int vst_cwct_apply(const float* x, float* y, int N, long L, const float* affine, const uint8_t* mask, int label,
+                   void* stream) {
+    return vst_cwct_apply_prec(x, y, N, L, affine, mask, label, VST_PREC_BF16X3, stream);
 }
 
 }  // extern "C"

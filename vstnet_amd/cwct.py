@@ -46,8 +46,15 @@ class MaskPlan:
 class cWCT(nn.Module):
     """Cholesky decomposition based WCT (HIP implementation)."""
 
-    def __init__(self, eps=2e-5, use_double=False, resize_masks=False):
+    def __init__(self, eps=2e-5, use_double=False, resize_masks=False, precision=None):
         super().__init__()
+        # arithmetic of the apply (y = T x + t0): "fp32" = exact fp32 kernels for every N; anything else lets unmasked
+        # N >= 64 codes (artistic mode) run on bf16 MFMA with split operands.  Follows RevResNet's knob by default.
+        import os
+        precision = precision or os.environ.get("VST_PRECISION", "f16x2")
+        if precision not in ("fp32", "bf16x3", "f16x2"):
+            raise ValueError("precision must be one of ['bf16x3', 'f16x2', 'fp32']")
+        self.precision = precision
         if use_double:
             raise NotImplementedError("vstnet_amd.cWCT(use_double=True): the HIP path factors and applies in fp32 (statistics "
                                       "are combined in fp64); an fp64 Cholesky / apply is not implemented")
@@ -111,8 +118,9 @@ class cWCT(nn.Module):
         if out is None:
             out = torch.empty_like(x2d)
         with torch.cuda.device(x2d.device):
-            _lib.check(_lib.lib().vst_cwct_apply(_ptr(x2d), _ptr(out), N, Lp, _ptr(affine), _ptr(mask), int(label),
-                                                 _stream_ptr()), "vst_cwct_apply")
+            prec = {"fp32": _lib.PREC_FP32, "bf16x3": _lib.PREC_BF16X3, "f16x2": _lib.PREC_F16X2}[self.precision]
+            _lib.check(_lib.lib().vst_cwct_apply_prec(_ptr(x2d), _ptr(out), N, Lp, _ptr(affine), _ptr(mask), int(label),
+                                                      prec, _stream_ptr()), "vst_cwct_apply_prec")
         return out
 
     @staticmethod

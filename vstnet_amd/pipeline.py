@@ -102,25 +102,44 @@ def prefetch(source, ahead=4):
     in the consumer."""
     q: queue.Queue = queue.Queue(maxsize=max(1, ahead))
     end = object()
+    stop = threading.Event()            # set when the consumer stops early (exception, break, generator close)
+
+    def put(item):
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
 
     def work():
         try:
             for item in source:
-                q.put(item)
-            q.put(end)
+                if not put(item):
+                    return              # consumer is gone: drop the decoded frames, end the thread
+            put(end)
         except BaseException as e:      # noqa: BLE001 — handed to the consumer
-            q.put(e)
+            put(e)
 
     t = threading.Thread(target=work, daemon=True)
     t.start()
-    while True:
-        item = q.get()
-        if item is end:
-            break
-        if isinstance(item, BaseException):
-            raise item
-        yield item
-    t.join()
+    try:
+        while True:
+            item = q.get()
+            if item is end:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+    finally:
+        stop.set()
+        while True:                     # release whatever the producer had queued
+            try:
+                q.get_nowait()
+            except queue.Empty:
+                break
+        t.join(timeout=5.0)
 
 
 class AsyncSink:

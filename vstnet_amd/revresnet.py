@@ -77,12 +77,14 @@ class RevResNet(nn.Module):
         self.sp_steps = sp_steps
         self.stack = nn.ModuleList([residual_block(ch, stride, mult=mult, kernel=kernel) for stride, ch in STACK])
         self.channel_reduction = channel_reduction(nChannels[-1], hidden_dim, sp_steps=sp_steps, kernel=kernel)
-        precision = precision or os.environ.get("VST_PRECISION", "bf16x3")
+        precision = precision or os.environ.get("VST_PRECISION", "f16x2")
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
         self.precision = precision
-        self._packed = None          # (device, blob tensor, bias tensors, NetWeights struct)
+        self._packed = None          # (device, blob tensor, bias tensors, NetWeights struct, parameter versions)
         self._workspace = None
+        # a PARENT module's load_state_dict never calls this module's load_state_dict: invalidate through the hook as well
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module._invalidate())
 
     # ------------------------------------------------------------------ weight packing
     def _blocks(self):
@@ -105,14 +107,22 @@ class RevResNet(nn.Module):
         """Call after editing parameters in place (the packed copies are rebuilt on the next call)."""
         self._invalidate()
 
+    def _param_versions(self, convs):
+        # in-place edits (param.data.copy_, optimizer.step, load_state_dict's copy_) bump a tensor's _version
+        return tuple(p._version for c in convs for p in (c.weight, c.bias)) + tuple(p.data_ptr() for c in convs for p in (c.weight, c.bias))
+
     def _ensure_packed(self, device):
-        if self._packed is not None and self._packed[0] == device:
-            return self._packed[3]
-        L = _lib.lib()
         convs = []
         for blk in self._blocks():
             for ci in CONV_IDX:
                 convs.append(blk.conv[ci])
+        versions = self._param_versions(convs)
+        if self._packed is not None and self._packed[0] == device and self._packed[4] == versions:
+            return self._packed[3]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise RuntimeError("vstnet_amd.RevResNet is an inference path (its outputs carry no autograd graph): call "
+                               ".eval() or run under torch.no_grad()")
+        L = _lib.lib()
         sizes = [L.vst_conv_packed_bytes(c.out_channels, c.in_channels) for c in convs]
         offsets = np.concatenate([[0], np.cumsum([(s + 255) // 256 * 256 for s in sizes])])
         blob = torch.empty(int(offsets[-1]), dtype=torch.uint8, device=device)
@@ -124,7 +134,7 @@ class RevResNet(nn.Module):
                 if c.weight.device != device:
                     raise RuntimeError(f"RevResNet parameters live on {c.weight.device}, input on {device}: call .to(device)")
                 w = c.weight.detach().to(torch.float32).contiguous()
-                b = c.bias.detach().to(torch.float32).contiguous()
+                b = c.bias.detach().to(torch.float32).clone()       # a copy: the packed weights and their bias age together
                 biases.append((w, b))
                 _lib.check(L.vst_pack_conv(C.c_void_p(w.data_ptr()), c.out_channels, c.in_channels,
                                            C.c_void_p(blob.data_ptr() + int(offsets[k])), st), "vst_pack_conv")
@@ -133,7 +143,7 @@ class RevResNet(nn.Module):
                 cw.bias = b.data_ptr()
             # one-off: the packed blob may be used from any stream afterwards (frames in flight on several streams)
             torch.cuda.current_stream(device).synchronize()
-        self._packed = (device, blob, biases, net)
+        self._packed = (device, blob, biases, net, versions)
         return net
 
     def _get_workspace(self, nbytes, device):
