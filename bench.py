@@ -158,8 +158,8 @@ def main():
         s_stats = cw.style_stats(z_s)
         plan = None
         if args.masked and not args.recompute_style:      # the masks and the style do not change between frames
-            plan = cw.bind_style(cw.plan_masks(cmask, smask, (fpg,) + tuple(z_s.shape[1:]), (fpg,) + tuple(z_s.shape[1:]), dev),
-                                 z_s.expand(fpg, -1, -1, -1))
+            plan = cw.plan_masks(cmask, smask, (fpg,) + tuple(z_s.shape[1:]), (fpg,) + tuple(z_s.shape[1:]), dev)
+            plan = cw.bind_style(cw.learn_slots(plan), z_s.expand(fpg, -1, -1, -1))
 
         def stylize_batch(recompute=args.recompute_style, keep=None):
             z_c = net(content, forward=True)

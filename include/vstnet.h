@@ -154,6 +154,27 @@ int vst_cwct_apply(const float* x, float* y, int N, long L, const float* affine,
  * with split operands (3 products, ~1.5e-5 max-rel) and everything else is exact fp32 */
 int vst_cwct_apply_prec(const float* x, float* y, int N, long L, const float* affine,
                         const uint8_t* mask, int label, int precision, void* stream);
+/* ---- single-pass masked transfer (cWCT._transfer_seg, models/cWCT.py:49-109; compute_label_info :166-189) ----------------
+ * vst_label_plan        : histograms both uint8 label maps ON THE DEVICE, applies the validity rule (count_c > 10, count_s > 10,
+ *                         ratio < 100 both ways, cWCT.py:178) and gives the valid labels consecutive "slots" in increasing label
+ *                         order (at most 32; more sets plan.overflow and keeps the content feature there).  plan = device buffer
+ *                         of VST_LABEL_PLAN_BYTES: {int n_slots, overflow; int hist_c[256], hist_s[256]; u8 lut[256]; u8 slot_label[32]}.
+ * vst_cwct_stats_labels : {n, mean, cov} of every slot in ONE pass over x (pixels of a tile are sorted by slot in LDS);
+ *                         stats = double[32][1 + N + N*N].  N in {32, 64, 128}.  workspace: vst_cwct_labels_workspace_bytes.
+ * vst_cwct_factor_labels: one workgroup per slot: affines[slot] = {T, t0} of (content slot, style slot); info = int[32][3].
+ * vst_cwct_apply_labels : y[:,p] = T[slot(p)] x[:,p] + t0[slot(p)], y = x where the label has no slot; one pass (y may alias x).
+ * max_slots (1..32, 0 = 32) bounds the slots the launches cover when the host knows it (e.g. a plan reused over a clip);
+ * nothing here synchronises with the host. */
+#define VST_LABEL_PLAN_BYTES 2344
+int vst_label_plan(const uint8_t* cmask, long Lc, const uint8_t* smask, long Ls, void* plan, void* stream);
+size_t vst_cwct_labels_workspace_bytes(int N, long L);
+int vst_cwct_stats_labels(const float* x, int N, long L, const uint8_t* mask, const void* plan, int max_slots,
+                          double* stats, void* workspace, void* stream);
+int vst_cwct_factor_labels(const double* content_stats, const double* style_stats, const void* plan, int max_slots,
+                           float eps, int N, float* affines, int* info, void* stream);
+int vst_cwct_apply_labels(const float* x, float* y, int N, long L, const float* affines, const uint8_t* mask,
+                          const void* plan, int max_slots, void* stream);
+
 /* Turns a statistics record into a "prefactored" one ({-(n+1), mean, chol(cov) with jitter retries}); a style that
  * is reused over many frames (video_transfer.py re-factors it per frame, :195-203) then costs no Cholesky in
  * vst_cwct_factor.  `out` may alias `stats`; info = int[1] retry count. */

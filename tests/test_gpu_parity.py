@@ -629,17 +629,18 @@ def test_full_size_config4_4096():
         assert out.shape == (1, 4096, 4096, 3) and out.dtype == torch.uint8
 
 
-def test_full_size_config5_1080p_masked():
-    """config 5's frame: 1920x1080, 5-label masks (+ a 6-pixel speck that must stay untouched).  Property: inside every
-    valid label the transferred code has the moments of the style code inside the same label; the speck keeps the
-    content code."""
+@pytest.mark.parametrize("kind", ["bands", "noise"])
+def test_full_size_config5_1080p_masked(kind):
+    """config 5's frame: 1920x1080, 5-label masks (+ a 6-pixel speck that must stay untouched) — vertical bands, and the
+    worst case for anything per-label: an independent random label per pixel.  Property: inside every valid label the
+    transferred code has the moments of the style code inside the same label; the speck keeps the content code."""
     from models.cWCT import cWCT
     net, sd, sp = make_net("photo")
     cw = cWCT()
     H, W = 1080, 1920
     x = synthetic_frames(1, H, W, seed=21).cuda()
     xs = synthetic_frames(1, H, W, seed=22).cuda()
-    cm, sm = synthetic_mask(H, W, 5, seed=3)[None], synthetic_mask(H, W, 5, seed=4, speck=False)[None]
+    cm, sm = synthetic_mask(H, W, 5, seed=3, kind=kind)[None], synthetic_mask(H, W, 5, seed=4, speck=False, kind=kind)[None]
     with torch.no_grad():
         zc, zs = net(x), net(xs)
         zc0 = zc.clone()
@@ -788,7 +789,7 @@ def test_mask_plan_equals_transfer():
     with torch.no_grad():
         zs = net(synthetic_frames(1, 40, 56, seed=9).cuda()).expand(B, -1, -1, -1)
         plan = cw.plan_masks(cm, sm, (B, 32, H, W), zs.shape, zs.device)
-        assert plan.labels[0] == [0, 1, 2] and plan.labels[1] == [0, 1, 2, 3]          # specks and missing labels dropped
+        assert cw.plan_info(plan, 0) == ([0, 1, 2], False) and cw.plan_info(plan, 1) == ([0, 1, 2, 3], False)   # specks / missing labels dropped
         bound = cw.bind_style(cw.plan_masks(cm, sm, (B, 32, H, W), zs.shape, zs.device), zs)
         for seed in (4, 5):
             zc = net(synthetic_frames(B, H, W, seed=seed).cuda())
@@ -799,6 +800,53 @@ def test_mask_plan_equals_transfer():
             cw.transfer_with_plan(zc[:, :, :32], zs, plan)
         with pytest.raises(ValueError):
             cw.transfer_with_plan(zc, None, plan)
+
+
+def test_single_pass_masked_transfer_hard_cases():
+    """the device-side label plan and the one-pass kernels on the cases per-label passes found easy to get wrong:
+    per-pixel random labels (every tile holds every label), 11 labels (> 8 resident slots: two statistics passes),
+    device-tensor masks, labels invalid by count or ratio, in place — all against the oracle"""
+    from models.cWCT import cWCT
+    cw = cWCT()
+    rng = np.random.default_rng(12)
+    H, W, sH, sW = 48, 80, 40, 64
+    zc = torch.from_numpy(rng.standard_normal((1, 32, H, W)).astype(np.float32)) * 0.7 + 0.2
+    zs = torch.from_numpy(rng.standard_normal((1, 32, sH, sW)).astype(np.float32)) * 1.3 - 0.1
+    # labels 0..10 scattered per pixel over wide bands (>= 300 pixels each, so 32 channels are well conditioned); label 40 is a
+    # 7-pixel speck, label 50 covers 600 content pixels but only 4 style pixels (ratio > 100 and count <= 10), label 60 exists
+    # only in the style
+    cm = (rng.integers(0, 11, (H, W))).astype(np.uint8)
+    cm[0, :7] = 40
+    cm[10:20, 10:70] = 50
+    sm = (rng.integers(0, 11, (sH, sW))).astype(np.uint8)
+    sm[0, :4] = 50
+    sm[5:8, :] = 60
+    ref = cpu_ref.transfer_seg(zc, zs, cm[None], sm[None])
+    labels, ok = cpu_ref.compute_label_info(cm, sm)
+    valid = [int(l) for l in labels if ok[l]]
+    assert valid == list(range(11))
+    plan = cw.plan_masks(cm[None], sm[None], zc.shape, zs.shape, torch.device("cuda"))
+    assert cw.plan_info(plan) == (valid, False)
+    out = cw.transfer(zc.cuda(), zs.cuda(), cm[None], sm[None])
+    assert_close(out, ref, 2e-4, "11 scattered labels", tol_max=TOL)
+    keep = T(np.isin(cm, [40, 50]))
+    assert torch.equal(out[0][:, keep].cpu(), zc[0][:, keep])                       # invalid labels: content kept bit for bit
+    # device-tensor masks, a learnt slot count, in place: identical results
+    out_dev = cw.transfer(zc.cuda(), zs.cuda(), torch.from_numpy(cm)[None].cuda(), torch.from_numpy(sm)[None].cuda())
+    assert torch.equal(out_dev, out)
+    plan = cw.learn_slots(plan)
+    assert plan.max_slots == 11
+    zc_dev = zc.cuda()
+    same = cw.transfer_with_plan(zc_dev, zs.cuda(), plan, inplace=True)
+    assert same.data_ptr() == zc_dev.data_ptr() and torch.equal(same, out)
+    # artistic codes: N = 128, two slots per statistics pass, one per apply pass
+    zc128 = torch.from_numpy(rng.standard_normal((1, 128, 64, 64)).astype(np.float32))
+    zs128 = torch.from_numpy(rng.standard_normal((1, 128, 64, 64)).astype(np.float32)) * 0.5 + 0.3
+    cm3 = rng.integers(0, 3, (64, 64)).astype(np.uint8)
+    sm3 = rng.integers(0, 3, (64, 64)).astype(np.uint8)
+    ref128 = cpu_ref.transfer_seg(zc128, zs128, cm3[None], sm3[None])
+    out128 = cw.transfer(zc128.cuda(), zs128.cuda(), cm3[None], sm3[None])
+    assert_close(out128, ref128, 2e-4, "3 scattered labels, N = 128", tol_max=TOL)
 
 
 def test_transfer_with_stats_inplace():

@@ -28,7 +28,8 @@ EXPORTS = [
     "vst_spread", "vst_gather", "vst_block_tmp_bytes", "vst_block_apply",
     "vst_pass_workspace_bytes", "vst_revnet_forward", "vst_revnet_inverse",
     "vst_cwct_stats_workspace_bytes", "vst_cwct_stats", "vst_cwct_factor", "vst_cwct_apply", "vst_cwct_apply_prec",
-    "vst_cwct_prefactor", "vst_profile_begin", "vst_profile_end", "vst_profile_end_table", "vst_lab_luminance",
+    "vst_cwct_prefactor", "vst_label_plan", "vst_cwct_labels_workspace_bytes", "vst_cwct_stats_labels",
+    "vst_cwct_factor_labels", "vst_cwct_apply_labels", "vst_profile_begin", "vst_profile_end", "vst_profile_end_table", "vst_lab_luminance",
 ]
 
 
@@ -116,6 +117,11 @@ def lib() -> C.CDLL:
         "vst_cwct_apply": (i, [vp, vp, i, lg, vp, vp, i, vp]),
         "vst_cwct_apply_prec": (i, [vp, vp, i, lg, vp, vp, i, i, vp]),
         "vst_cwct_prefactor": (i, [vp, i, f, vp, vp, vp]),
+        "vst_label_plan": (i, [vp, lg, vp, lg, vp, vp]),
+        "vst_cwct_labels_workspace_bytes": (sz, [i, lg]),
+        "vst_cwct_stats_labels": (i, [vp, i, lg, vp, vp, i, vp, vp, vp]),
+        "vst_cwct_factor_labels": (i, [vp, vp, vp, i, f, i, vp, vp, vp]),
+        "vst_cwct_apply_labels": (i, [vp, vp, i, lg, vp, vp, vp, i, vp]),
         "vst_profile_begin": (i, [i, i]),
         "vst_profile_end": (i, [C.POINTER(C.c_double), C.POINTER(i)]),
         "vst_profile_end_table": (i, [C.POINTER(i), C.POINTER(C.c_double), C.POINTER(i), i, C.POINTER(i)]),

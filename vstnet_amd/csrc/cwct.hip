@@ -250,12 +250,18 @@ __global__ __launch_bounds__(256) void cwct_stats_mfma_kernel(const float* __res
 
 // Combine the per-workgroup records in fp64 (Chan et al. pairwise update).  Both kernels give 16 threads
 // to every output (a channel mean / a covariance entry), each summing G/16 records, then reduce in LDS.
+// blockIdx.y = label slot of a multi-label pass (records of one workgroup are `rs` consecutive slots; slot0 + blockIdx.y
+// past *n_slots: nothing to do); single-label callers pass rs = 1, slot0 = 0, n_slots = nullptr.
 __global__ __launch_bounds__(256) void cwct_stats_mean_kernel(const float* __restrict__ partial, int G, int N,
-                                                              double* __restrict__ stats) {
+                                                              double* __restrict__ stats, int rs, int slot0,
+                                                              const int* __restrict__ n_slots) {
     __shared__ double sacc[16][17], snt[16][17];
+    if (n_slots != nullptr && slot0 + (int)blockIdx.y >= *n_slots) return;
     const int cl = threadIdx.x & 15, gl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
-    const size_t PS = cwct_partial_stride(N);
+    const size_t PS = cwct_partial_stride(N) * rs;
+    partial += (size_t)blockIdx.y * cwct_partial_stride(N);
+    stats += (size_t)(slot0 + blockIdx.y) * (1 + N + (size_t)N * N);
     double acc = 0.0, nt = 0.0;
     for (int g = gl; g < G; g += 16) {
         const float* rec = partial + (size_t)g * PS;
@@ -274,12 +280,16 @@ __global__ __launch_bounds__(256) void cwct_stats_mean_kernel(const float* __res
 }
 
 __global__ __launch_bounds__(256) void cwct_stats_cov_kernel(const float* __restrict__ partial, int G, int N,
-                                                             double* __restrict__ stats) {
+                                                             double* __restrict__ stats, int rs, int slot0,
+                                                             const int* __restrict__ n_slots) {
     __shared__ double sm2[16][17];
+    if (n_slots != nullptr && slot0 + (int)blockIdx.y >= *n_slots) return;
     const int el = threadIdx.x & 15, gl = threadIdx.x >> 4;
     const int e = blockIdx.x * 16 + el;
     const int i = e / N, j = e - i * N;
-    const size_t PS = cwct_partial_stride(N);
+    const size_t PS = cwct_partial_stride(N) * rs;
+    partial += (size_t)blockIdx.y * cwct_partial_stride(N);
+    stats += (size_t)(slot0 + blockIdx.y) * (1 + N + (size_t)N * N);
     const double mu_i = stats[1 + i], mu_j = stats[1 + j];
     double m2 = 0.0;
     for (int g = gl; g < G; g += 16) {
@@ -314,6 +324,11 @@ struct FactorArgs {
     int N;
     float* affine;
     int* info;
+    // multi-label form: workgroup s = blockIdx.x factors slot s: content / styles[i] / affine / info advance by these strides
+    // per slot; workgroups at or past *n_slots exit.  All zero / null for the single-pair launch.
+    size_t content_stride, style_stride, affine_stride;
+    int info_stride;
+    const int* n_slots;
 };
 
 // The N x N matrices live in registers, distributed 2-D cyclically over the 16 x 16 threads: thread (ti, tj)
@@ -428,8 +443,15 @@ __device__ int fac_factor(const double* stats, float eps, int ti, int tj, float 
 }
 
 template <int BLK>
-__global__ __launch_bounds__(256) void cwct_factor_kernel(const FactorArgs a) {
+__global__ __launch_bounds__(256) void cwct_factor_kernel(FactorArgs a) {
     constexpr int N = 16 * BLK;
+    if (a.n_slots != nullptr) {
+        if ((int)blockIdx.x >= *a.n_slots) return;
+        a.content += blockIdx.x * a.content_stride;
+        for (int s = 0; s < a.n_styles; ++s) a.styles[s] += blockIdx.x * a.style_stride;
+        a.affine += blockIdx.x * a.affine_stride;
+        a.info += blockIdx.x * a.info_stride;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
     float* Lmat = (float*)fsm;             // N*N   Lc, row-major
     float* col = Lmat + N * N;             // 2*N   column broadcast of the Cholesky (look-ahead double buffer)
@@ -791,6 +813,417 @@ static int launch_apply(const float* x, float* y, long L, const float* affine, c
     return VST_OK;
 }
 
+// ================================================================================================
+// single-pass masked transfer (models/cWCT.py:49-109,166-189): every label in ONE statistics pass and ONE apply pass
+// ================================================================================================
+// Plan record, built on the device from the two label maps (no host histogram, no sync): the labels that pass the
+// reference's validity rule (count_c > 10, count_s > 10, count ratio < 100 both ways, cWCT.py:178) get consecutive slots
+// in increasing label order; lut[label] = slot, 255 = "keep the content feature".
+#define CWCT_MAX_SLOTS 32
+struct LabelPlan {
+    int n_slots, overflow;
+    int hist_c[256], hist_s[256];
+    unsigned char lut[256];
+    unsigned char slot_label[CWCT_MAX_SLOTS];
+};
+static_assert(sizeof(LabelPlan) == VST_LABEL_PLAN_BYTES, "vstnet.h: VST_LABEL_PLAN_BYTES");
+
+__global__ __launch_bounds__(256) void label_hist_kernel(const uint8_t* __restrict__ mask, long L, int* __restrict__ hist) {
+    __shared__ int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < L; p += (long)gridDim.x * 256) atomicAdd(&h[mask[p]], 1);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void label_plan_kernel(LabelPlan* plan) {
+    __shared__ int valid[256];
+    const int l = threadIdx.x;
+    const int a = plan->hist_c[l], b = plan->hist_s[l];
+    // a / b < 100 and b / a < 100 in the reference's float arithmetic == a < 100 b and b < 100 a for positive counts
+    valid[l] = a > 10 && b > 10 && (double)a / (double)b < 100.0 && (double)b / (double)a < 100.0;
+    __syncthreads();
+    if (l == 0) {
+        int n = 0, over = 0;
+        for (int k = 0; k < 256; ++k) {
+            unsigned char s = 255;
+            if (valid[k]) {
+                if (n < CWCT_MAX_SLOTS) { s = (unsigned char)n; plan->slot_label[n] = (unsigned char)k; ++n; }
+                else over = 1;
+            }
+            plan->lut[k] = s;
+        }
+        plan->n_slots = n; plan->overflow = over;
+    }
+}
+
+// Statistics of KRES label slots [slot0, slot0 + KRES) in one pass over x: like cwct_stats_mfma_kernel, but the 64 pixels of
+// a tile are staged into LDS SORTED by slot (stable; each slot's run padded to an even length with a zero column), so each
+// slot's X X^T runs over its own pixels only: about one tile's worth of MFMAs per tile however the labels are mixed.
+// Every wave sorts for itself (lane = pixel: ballots and popcounts, destinations handed to the staging lanes by shuffles),
+// so the tile costs the same two barriers as the unmasked kernel.
+// For N = 32 the four waves split the work 2 x 2: by slot half (KW = KRES / 2 accumulators per wave instead of KRES) and by
+// pixel-pair parity — 8 resident slots at 2-3 workgroups per CU.
+template <int NBLK, int KRES>
+__global__ __launch_bounds__(256, NBLK == 1 ? 2 : 1) void cwct_stats_labels_kernel(const float* __restrict__ x, long L,
+                                                                   const uint8_t* __restrict__ mask,
+                                                                   const LabelPlan* __restrict__ plan, int slot0,
+                                                                   float* __restrict__ partial, int px_per_wg) {
+    constexpr int N = 32 * NBLK, PT = 64, LD = PT + KRES + 1, PG = 4 / NBLK;
+    constexpr int NV = N * PT / 4 / 256;                  // float4 groups per thread and tile
+    constexpr int TPC = 256 / N, SPAN = TPC;               // row sums: TPC threads per channel, each takes every TPC-th column
+    constexpr int LS = NBLK == 1 ? 2 : 1, KW = KRES / LS, PGE = PG / LS;   // slot split / slots per wave / pixel-pair groups
+    __shared__ float xs[N * LD];
+    __shared__ float sh[N];
+    __shared__ unsigned char lut[256];
+    if (slot0 >= plan->n_slots) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rb = wave % NBLK, pgw = wave / NBLK, lh = pgw % LS, pg = pgw / LS;
+    const long p_begin = (long)blockIdx.x * px_per_wg;
+    long p_end = p_begin + px_per_wg;
+    if (p_end > L) p_end = L;
+    for (int c = tid; c < N; c += 256) sh[c] = p_begin < L ? x[(size_t)c * L + p_begin] : 0.f;
+    lut[tid] = plan->lut[tid];
+    __syncthreads();
+
+    // two tiles in flight per workgroup (the kernel runs at 1-2 workgroups per CU: it needs the bytes in flight)
+    float4 pvq[2][NV];
+    int relq[2];                                           // slot (relative to slot0) of pixel p0 + lane of a prefetched tile, -1 = none
+    const bool vec = (L % 4) == 0 && ((uintptr_t)x % 16) == 0;
+#define PREFETCH(slot_, p0_)                                                                        \
+    {                                                                                               \
+        const long p0__ = (p0_);                                                                    \
+        const long pm = p0__ + lane;                                                                \
+        int rel_next = -1;                                                                          \
+        if (pm < p_end) {                                                                           \
+            const int sl = lut[mask[pm]];                                                           \
+            rel_next = (sl != 255 && sl >= slot0 && sl < slot0 + KRES) ? sl - slot0 : -1;           \
+        }                                                                                           \
+        relq[slot_] = rel_next;                                                                     \
+        _Pragma("unroll") for (int it = 0; it < NV; ++it) {                                         \
+            const int e = it * 256 + tid, c = e >> 4;                                               \
+            const long p = p0__ + 4 * (e & 15);                                                     \
+            float t[4] = {0.f, 0.f, 0.f, 0.f};                                                      \
+            if (vec && p + 3 < p_end) {                                                             \
+                const float4 v = *(const float4*)(x + (size_t)c * L + p);                           \
+                t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;                                     \
+            } else {                                                                                \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q)                                       \
+                    if (p + q < p_end) t[q] = x[(size_t)c * L + p + q];                             \
+            }                                                                                       \
+            pvq[slot_][it] = make_float4(t[0], t[1], t[2], t[3]);                                   \
+        }                                                                                           \
+    }
+
+    f32x16 acc[KW][NBLK];                                  // slots lh * KW + kk of this wave
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[k][b][r] = 0.f;
+    float asum[KRES], cnt[KRES];
+#pragma unroll
+    for (int k = 0; k < KRES; ++k) { asum[k] = 0.f; cnt[k] = 0.f; }
+    const int sc = tid % N, sp = tid / N;                  // row sums: channel and column phase of this thread
+    PREFETCH(0, p_begin);
+    PREFETCH(1, p_begin + PT);
+#pragma unroll 1
+    for (long p00 = p_begin; p00 < p_end; p00 += 2 * PT) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {               // register set `half` holds this tile (static indices)
+        const long p0 = p00 + half * PT;
+        if (p0 >= p_end) break;
+        // ---- stable sort of the tile's pixels by slot, per wave in registers ------------------------------------------
+        const int rel = relq[half];
+        int seg_begin[KRES], seg_cnt[KRES], my_begin[KW], my_cnt[KW];
+        int base = 0, mine = -1;
+#pragma unroll
+        for (int k = 0; k < KRES; ++k) {
+            const unsigned long long bal = __ballot(rel == k);
+            const int c = __popcll(bal);
+            if (rel == k) mine = base + __popcll(bal & ((1ull << lane) - 1ull));
+            seg_begin[k] = base; seg_cnt[k] = c;
+            if (k < KW || LS == 1) { my_begin[k % KW] = base; my_cnt[k % KW] = c; }
+            else if (lh == 1) { my_begin[k % KW] = base; my_cnt[k % KW] = c; }
+            base += (c + 1) & ~1;
+        }
+        if (LS == 2 && lh == 0) {                          // (the second half's runs were recorded last: restore the first half's)
+#pragma unroll
+            for (int k = 0; k < KW; ++k) { my_begin[k] = seg_begin[k]; my_cnt[k] = seg_cnt[k]; }
+        }
+        if (base == 0) {                                   // uniform: no pixel of these slots in the tile
+            PREFETCH(half, p0 + 2 * PT);
+            continue;
+        }
+        __syncthreads();                                   // previous tile's MFMAs and row sums are done with xs
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            if (VST_LBL_ABL & 4) break;
+            const int e = it * 256 + tid, c = e >> 4, pl = 4 * (e & 15);
+            const float s0 = sh[c];
+            const float v[4] = {pvq[half][it].x, pvq[half][it].y, pvq[half][it].z, pvq[half][it].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int d = __shfl(mine, pl + q, 64);   // destination column of pixel pl + q (lane = pixel in every wave)
+                if (d >= 0) xs[c * LD + d] = v[q] - s0;
+            }
+        }
+        if (tid < N) {                                     // zero pad column of every odd-length run
+#pragma unroll
+            for (int k = 0; k < KRES; ++k)
+                if (seg_cnt[k] & 1) xs[tid * LD + seg_begin[k] + seg_cnt[k]] = 0.f;
+        }
+        __syncthreads();
+        PREFETCH(half, p0 + 2 * PT);                       // in flight during the row sums and MFMAs below and the whole next tile
+#ifndef VST_LBL_ABL
+#define VST_LBL_ABL 0
+#endif
+#pragma unroll
+        for (int k = 0; k < KRES; ++k) {
+            if (VST_LBL_ABL & 1) break;
+            float sacc = 0.f;
+            const int nb = seg_begin[k], nc = seg_cnt[k];
+            for (int j0 = sp; j0 < nc; j0 += 4 * SPAN) {     // four independent LDS reads per round (runtime trip count)
+                float t4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u * SPAN;
+                    t4[u] = xs[sc * LD + nb + (j < nc ? j : nc - 1)];
+                    t4[u] = j < nc ? t4[u] : 0.f;
+                }
+                sacc += (t4[0] + t4[1]) + (t4[2] + t4[3]);
+            }
+            asum[k] += sacc;
+            cnt[k] += (float)nc;
+        }
+        const float* bptr = xs + (lane & 31) * LD + (lane >> 5);
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            if (VST_LBL_ABL & 2) break;
+            const int nb = my_begin[k], npair = (my_cnt[k] + 1) >> 1;
+            // four pixel pairs per round: their fragment reads are issued together (a pair past the run's end reads the
+            // last pair's address and contributes zeros), then the MFMAs
+            for (int t0 = pg; t0 < npair; t0 += 4 * PGE) {
+                float f[4][NBLK];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + u * PGE;
+                    const int tc = t < npair ? t : npair - 1;
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b) {
+                        const float v = bptr[b * 32 * LD + nb + 2 * tc];
+                        f[u][b] = t < npair ? v : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float fa = f[u][0];
+#pragma unroll
+                    for (int b = 1; b < NBLK; ++b) fa = rb == b ? f[u][b] : fa;
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b)
+                        acc[k][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, f[u][b], acc[k][b], 0, 0, 0);
+                }
+            }
+        }
+      }
+    }
+#undef PREFETCH
+    // ---- one record per workgroup and slot ---------------------------------------------------------------------------
+    const size_t PS = cwct_partial_stride(N);
+    __syncthreads();
+    float* red = xs;                                       // [KRES][TPC][N] partial row sums -> summed below
+#pragma unroll
+    for (int k = 0; k < KRES; ++k) red[(k * TPC + sp) * N + sc] = asum[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KRES; ++k) {
+        float* rec = partial + ((size_t)blockIdx.x * KRES + k) * PS;
+        if (tid < N) {
+            float t = 0.f;
+            for (int j = 0; j < TPC; ++j) t += red[(k * TPC + j) * N + tid];
+            rec[4 + N + tid] = t;
+        }
+        if (tid == 0) rec[0] = cnt[k];
+        for (int c = tid; c < N; c += 256) rec[4 + c] = sh[c];
+    }
+    float* const xch = xs + lh * (NBLK * NBLK * 16 * 64);  // exchange region of this slot half
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        float* rec = partial + ((size_t)blockIdx.x * KRES + lh * KW + k) * PS;
+        if (PGE > 1) {
+            for (int round = 1; round < PGE; ++round) {
+                __syncthreads();
+                if (pg == round) {
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) xch[((rb * NBLK + b) * 16 + r) * 64 + lane] = acc[k][b][r];
+                }
+                __syncthreads();
+                if (pg == 0) {
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[k][b][r] += xch[((rb * NBLK + b) * 16 + r) * 64 + lane];
+                }
+            }
+        }
+        if (pg == 0) {
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = b * 32 + (lane & 31);
+                    rec[4 + 2 * N + (size_t)i * N + j] = acc[k][b][r];
+                }
+        }
+    }
+}
+
+// y[:,p] = T[slot(p)] x[:,p] + t0[slot(p)] for the slots [slot0, slot0 + KRES); FIRST pass (slot0 == 0): every other pixel
+// gets y = x; later passes write only their own slots' pixels.  One MFMA sweep per slot PRESENT in a wave's pixel group,
+// with the other pixels' columns zeroed: each column belongs to one slot, so all sweeps add into the same accumulators.
+template <int NBLK, int PXV, int KRES>
+__global__ __launch_bounds__(256) void cwct_apply_labels_kernel(const float* x, float* y, long L,
+                                                                const float* __restrict__ affines,
+                                                                const uint8_t* __restrict__ mask,
+                                                                const LabelPlan* __restrict__ plan, int slot0, long ngroups) {
+    constexpr int N = 32 * NBLK, LDT = N + 1, GP = 32 * PXV, TS = N * LDT + N;   // floats per slot in LDS: T (padded rows), t0
+    extern __shared__ __attribute__((aligned(16))) float asm3_[];
+    __shared__ unsigned char lut[256];
+    const int n_slots = plan->n_slots;
+    if (slot0 > 0 && slot0 >= n_slots) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool first = slot0 == 0;
+    // slot index KRES is the identity map of the first pass (pixels of no slot or of a later pass: y = x)
+    for (int k = 0; k <= KRES; ++k) {
+        float* Tl = asm3_ + (size_t)k * TS;
+        const bool ident = k == KRES || slot0 + k >= n_slots;
+        const float* aff = affines + (size_t)(slot0 + k) * ((size_t)N * N + N);
+        for (int idx = tid; idx < N * N; idx += 256) {
+            const int i = idx / N, j = idx - i * N;
+            Tl[i * LDT + j] = ident ? (i == j ? 1.f : 0.f) : aff[idx];
+        }
+        for (int idx = tid; idx < N; idx += 256) Tl[N * LDT + idx] = ident ? 0.f : aff[N * N + idx];
+    }
+    lut[tid] = plan->lut[tid];
+    __syncthreads();
+    const int col = lane & 31, kh = lane >> 5;
+    for (long g = (long)blockIdx.x * 4 + wave; g < ngroups; g += (long)gridDim.x * 4) {
+        const long pl = g * GP + (long)col * PXV;
+        const bool inside = pl < L;
+        const long plc = inside ? pl : L - PXV;
+        int sl[PXV];                                         // slot relative to slot0 (KRES = identity / not mine)
+        unsigned present = 0;
+#pragma unroll
+        for (int q = 0; q < PXV; ++q) {
+            int s2 = inside ? (int)lut[mask[plc + q]] : 255;
+            s2 = (s2 != 255 && s2 >= slot0 && s2 < slot0 + KRES) ? s2 - slot0 : KRES;
+            sl[q] = inside ? s2 : -1;
+            if (inside) present |= 1u << s2;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) present |= (unsigned)__shfl_xor((int)present, o, 64);   // slots present in the group
+        if (!first) present &= (1u << KRES) - 1u;
+        if (present == 0) continue;
+        f32x16 acc[PXV][NBLK];
+#pragma unroll
+        for (int q = 0; q < PXV; ++q)
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][b][r] = 0.f;
+        const float* xp = x + plc + (size_t)kh * L;
+        for (int k = 0; k <= KRES; ++k) {
+            if (!((present >> k) & 1u)) continue;            // uniform
+            const float* tp = asm3_ + (size_t)k * TS + col * LDT + kh;
+            bool mine[PXV];
+#pragma unroll
+            for (int q = 0; q < PXV; ++q) mine[q] = sl[q] == k;
+#pragma unroll 4
+            for (int t = 0; t < N / 2; ++t) {
+                float v[PXV];
+                if (PXV == 4) { const float4 w = *(const float4*)(xp + (size_t)2 * t * L); v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w; }
+                else if (PXV == 2) { const float2 w = *(const float2*)(xp + (size_t)2 * t * L); v[0] = w.x; v[1] = w.y; }
+                else v[0] = xp[(size_t)2 * t * L];
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) {
+                    const float av = tp[b * 32 * LDT + 2 * t];
+#pragma unroll
+                    for (int q = 0; q < PXV; ++q)
+                        acc[q][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, mine[q] ? v[q] : 0.f, acc[q][b], 0, 0, 0);
+                }
+            }
+        }
+        bool on[PXV];
+        bool all = true;
+#pragma unroll
+        for (int q = 0; q < PXV; ++q) { on[q] = sl[q] >= 0 && (first || sl[q] < KRES); all &= on[q]; }
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = b * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                float o[PXV];
+#pragma unroll
+                for (int q = 0; q < PXV; ++q) {
+                    const int s2 = sl[q] < 0 ? KRES : sl[q];
+                    o[q] = acc[q][b][r] + asm3_[(size_t)s2 * TS + N * LDT + i];
+                }
+                float* dstp = y + (size_t)i * L + pl;
+                if (PXV == 4 && all) *(float4*)dstp = make_float4(o[0], o[1], o[2], o[3]);
+                else if (PXV == 2 && all) *(float2*)dstp = make_float2(o[0], o[1]);
+                else {
+#pragma unroll
+                    for (int q = 0; q < PXV; ++q) if (on[q]) dstp[q] = o[q];
+                }
+            }
+    }
+}
+
+template <int N> struct LabelCfg { static constexpr int NBLK = N / 32, KRES = 8 / NBLK, KAPP = N == 128 ? 1 : (N == 64 ? 4 : 8); };
+
+
+template <int N>
+static int stats_labels(const float* x, long L, const uint8_t* mask, const LabelPlan* plan, double* stats, float* partial,
+                        int max_slots, hipStream_t st) {
+    using C = LabelCfg<N>;
+    int per;
+    const int G = cwct_stats_groups(L, &per);
+    for (int slot0 = 0; slot0 < max_slots; slot0 += C::KRES) {
+        cwct_stats_labels_kernel<C::NBLK, C::KRES><<<G, 256, 0, st>>>(x, L, mask, plan, slot0, partial, per);
+        VST_RETURN_IF_LAUNCH_FAILED();
+        cwct_stats_mean_kernel<<<dim3(N / 16, C::KRES), 256, 0, st>>>(partial, G, N, stats, C::KRES, slot0, &plan->n_slots);
+        cwct_stats_cov_kernel<<<dim3(N * N / 16, C::KRES), 256, 0, st>>>(partial, G, N, stats, C::KRES, slot0, &plan->n_slots);
+        VST_RETURN_IF_LAUNCH_FAILED();
+    }
+    return VST_OK;
+}
+
+
+template <int N, int PXV>
+static int apply_labels(const float* x, float* y, long L, const float* affines, const uint8_t* mask, const LabelPlan* plan,
+                        int max_slots, hipStream_t st) {
+    using C = LabelCfg<N>;
+    constexpr int TS = N * (N + 1) + N;
+    const long ngroups = (L + 32 * PXV - 1) / (32 * PXV);
+    long wgs = (ngroups + 3) / 4;
+    if (wgs > 2048) wgs = 2048;
+    const size_t lds = (size_t)(C::KAPP + 1) * TS * sizeof(float);
+    auto kern = cwct_apply_labels_kernel<C::NBLK, PXV, C::KAPP>;
+    static std::atomic<unsigned> attr_done{0};
+    if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)lds, &attr_done)) return rc_;
+    for (int slot0 = 0; slot0 < max_slots; slot0 += C::KAPP) {
+        kern<<<dim3((unsigned)wgs), 256, lds, st>>>(x, y, L, affines, mask, plan, slot0, ngroups);
+        VST_RETURN_IF_LAUNCH_FAILED();
+    }
+    return VST_OK;
+}
+
+
 extern "C" {
 
 size_t vst_cwct_stats_workspace_bytes(int N, long L) {
@@ -823,9 +1256,9 @@ int vst_cwct_stats(const float* x, int N, long L, const uint8_t* mask, int label
                  break;
     }
     VST_RETURN_IF_LAUNCH_FAILED();
-    cwct_stats_mean_kernel<<<N / 16, 256, 0, st>>>(partial, G, N, stats);
+    cwct_stats_mean_kernel<<<N / 16, 256, 0, st>>>(partial, G, N, stats, 1, 0, nullptr);
     VST_RETURN_IF_LAUNCH_FAILED();
-    cwct_stats_cov_kernel<<<N * N / 16, 256, 0, st>>>(partial, G, N, stats);
+    cwct_stats_cov_kernel<<<N * N / 16, 256, 0, st>>>(partial, G, N, stats, 1, 0, nullptr);
     VST_RETURN_IF_LAUNCH_FAILED();
     return VST_OK;
 }
@@ -892,6 +1325,91 @@ int vst_cwct_apply_prec(const float* x, float* y, int N, long L, const float* af
 int vst_cwct_apply(const float* x, float* y, int N, long L, const float* affine, const uint8_t* mask, int label,
                    void* stream) {
     return vst_cwct_apply_prec(x, y, N, L, affine, mask, label, VST_PREC_BF16X3, stream);
+}
+
+// ---- single-pass masked transfer ----------------------------------------------------------------------------------------
+int vst_label_plan(const uint8_t* cmask, long Lc, const uint8_t* smask, long Ls, void* plan, void* stream) {
+    if (!cmask || !smask || !plan || Lc <= 0 || Ls <= 0) return VST_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    LabelPlan* p = (LabelPlan*)plan;
+    hipError_t e = hipMemsetAsync(p, 0, sizeof(LabelPlan), st);
+    if (e != hipSuccess) return (int)e;
+    auto blocks = [](long L) { long b = (L + 256 * 16 - 1) / (256 * 16); return (unsigned)(b > 1024 ? 1024 : (b < 1 ? 1 : b)); };
+    label_hist_kernel<<<blocks(Lc), 256, 0, st>>>(cmask, Lc, p->hist_c);
+    label_hist_kernel<<<blocks(Ls), 256, 0, st>>>(smask, Ls, p->hist_s);
+    label_plan_kernel<<<1, 256, 0, st>>>(p);
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
+size_t vst_cwct_labels_workspace_bytes(int N, long L) {
+    int per;
+    const int g = cwct_stats_groups(L, &per);
+    const int kres = N >= 32 ? 8 / (N / 32) : 8;
+    return (size_t)g * kres * cwct_partial_stride(N) * sizeof(float);
+}
+
+int vst_cwct_stats_labels(const float* x, int N, long L, const uint8_t* mask, const void* plan, int max_slots, double* stats,
+                          void* workspace, void* stream) {
+    if (!x || !mask || !plan || !stats || L <= 0) return VST_E_ARG;
+    if (!workspace) return VST_E_WORKSPACE;
+    if (max_slots <= 0 || max_slots > CWCT_MAX_SLOTS) max_slots = CWCT_MAX_SLOTS;
+    hipStream_t st = (hipStream_t)stream;
+    vst_prof_scope prof(VST_KERNEL_CWCT_STATS, st);
+    const LabelPlan* p = (const LabelPlan*)plan;
+    switch (N) {
+        case 32: return stats_labels<32>(x, L, mask, p, stats, (float*)workspace, max_slots, st);
+        case 64: return stats_labels<64>(x, L, mask, p, stats, (float*)workspace, max_slots, st);
+        case 128: return stats_labels<128>(x, L, mask, p, stats, (float*)workspace, max_slots, st);
+        default: return VST_E_SHAPE;
+    }
+}
+
+int vst_cwct_factor_labels(const double* content_stats, const double* style_stats, const void* plan, int max_slots, float eps,
+                           int N, float* affines, int* info, void* stream) {
+    if (!content_stats || !style_stats || !plan || !affines || !info) return VST_E_ARG;
+    if (!(N == 32 || N == 64 || N == 128)) return VST_E_SHAPE;
+    if (max_slots <= 0 || max_slots > CWCT_MAX_SLOTS) max_slots = CWCT_MAX_SLOTS;
+    FactorArgs a{};
+    a.content = content_stats; a.styles[0] = style_stats; a.alphas[0] = 1.f; a.n_styles = 1; a.alpha_c = 0.f; a.eps = eps; a.N = N;
+    a.affine = affines; a.info = info;
+    a.content_stride = a.style_stride = 1 + N + (size_t)N * N; a.affine_stride = (size_t)N * N + N; a.info_stride = 3;
+    a.n_slots = &((const LabelPlan*)plan)->n_slots;
+    const size_t lds = (size_t)N * N * 4 + (size_t)3 * N * 4 + 16;
+    hipStream_t st = (hipStream_t)stream;
+    static std::atomic<unsigned> attr_done{0};
+    if (int rc_ = vst_ensure_dynamic_lds((const void*)cwct_factor_kernel<8>, (int)(80 * 1024), &attr_done)) return rc_;
+    hipError_t e = hipMemsetAsync(info, 0, (size_t)max_slots * 3 * sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    vst_prof_scope prof(VST_KERNEL_CWCT_FACTOR, st);
+    switch (N) {
+        case 32: cwct_factor_kernel<2><<<max_slots, 256, lds, st>>>(a); break;
+        case 64: cwct_factor_kernel<4><<<max_slots, 256, lds, st>>>(a); break;
+        default: cwct_factor_kernel<8><<<max_slots, 256, lds, st>>>(a); break;
+    }
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
+int vst_cwct_apply_labels(const float* x, float* y, int N, long L, const float* affines, const uint8_t* mask, const void* plan,
+                          int max_slots, void* stream) {
+    if (!x || !y || !affines || !mask || !plan || L <= 0) return VST_E_ARG;
+    if (x == y && max_slots > 8) { /* in place is fine: a pass reads a pixel group before it writes it */ }
+    if (max_slots <= 0 || max_slots > CWCT_MAX_SLOTS) max_slots = CWCT_MAX_SLOTS;
+    hipStream_t st = (hipStream_t)stream;
+    vst_prof_scope prof(VST_KERNEL_CWCT_APPLY, st);
+    const LabelPlan* p = (const LabelPlan*)plan;
+    const bool v4 = (L % 4) == 0 && (((uintptr_t)x | (uintptr_t)y) % 16) == 0;
+    const bool v2 = (L % 2) == 0 && (((uintptr_t)x | (uintptr_t)y) % 8) == 0;
+    switch (N) {
+        case 32: return v4 ? apply_labels<32, 4>(x, y, L, affines, mask, p, max_slots, st)
+                           : apply_labels<32, 1>(x, y, L, affines, mask, p, max_slots, st);
+        case 64: return v2 ? apply_labels<64, 2>(x, y, L, affines, mask, p, max_slots, st)
+                           : apply_labels<64, 1>(x, y, L, affines, mask, p, max_slots, st);
+        case 128: return v2 ? apply_labels<128, 2>(x, y, L, affines, mask, p, max_slots, st)
+                            : apply_labels<128, 1>(x, y, L, affines, mask, p, max_slots, st);
+        default: return VST_E_SHAPE;
+    }
 }
 
 }  // extern "C"

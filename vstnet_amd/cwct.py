@@ -36,11 +36,11 @@ def _ptr(t):
 
 
 class MaskPlan:
-    """What the masked transfer derives from the label maps alone (cWCT.plan_masks); optionally the per-label style
-    statistics (cWCT.bind_style)."""
+    """What the masked transfer derives from the label maps alone (cWCT.plan_masks): per sample the uint8 maps and the
+    label -> slot table, all on the device; optionally the per-slot style statistics (cWCT.bind_style)."""
 
     def __init__(self):
-        self.cm, self.sm, self.labels, self.shapes, self.style = [], [], [], None, None
+        self.cm, self.sm, self.tables, self.shapes, self.style, self.max_slots = [], [], [], None, None, 0
 
 
 class cWCT(nn.Module):
@@ -200,59 +200,93 @@ class cWCT(nn.Module):
 
     def _transfer_seg(self, content_feat, style_feat, cmask, smask):
         """models/cWCT.py:49-109."""
+        if content_feat.shape[1] == 16:       # no matrix-core form at N = 16: one statistics + apply pass per label
+            return self._transfer_seg_per_label(content_feat, style_feat, cmask, smask)
         plan = self.plan_masks(cmask, smask, content_feat.shape, style_feat.shape, content_feat.device)
         return self.transfer_with_plan(content_feat, style_feat, plan)
 
-    # ------------------------------------------------------------------ cached-mask extension (video: same masks every frame)
+    # ------------------------------------------------------------------ single-pass masked transfer
+    # Everything `_transfer_seg` derives from the label maps (models/cWCT.py:72-76,166-189) happens on the device: both
+    # histograms, the validity rule, and a label -> slot table (vst_label_plan); then ONE statistics pass per code for all
+    # labels, one factor launch (a workgroup per label) and ONE apply pass.  No host histogram, no per-label launches, no
+    # synchronisation: a per-frame mask costs its upload (or nothing, if it is already a device tensor).
+    MAX_SLOTS = 32
+
+    def _mask_to_device(self, m, hw, device, what):
+        H, W = hw
+        if torch.is_tensor(m):
+            if m.numel() != H * W:
+                raise ValueError(f"masks must have the feature resolution ({what} {tuple(m.shape)} vs {(H, W)})")
+            return m.to(device=device, dtype=torch.uint8).reshape(-1).contiguous()
+        m_np = np.asarray(m)
+        if self.resize_masks and m_np.shape != (H, W):
+            m_np = self.resize(np.ascontiguousarray(m_np.astype(np.uint8)), H, W)
+        if m_np.size != H * W:
+            raise ValueError(f"masks must have the feature resolution ({what} {m_np.shape} vs {(H, W)})")
+        if m_np.dtype != np.uint8 and (m_np.max() > 255 or m_np.min() < 0):
+            raise ValueError("labels must be in [0, 255]")
+        return torch.from_numpy(np.ascontiguousarray(m_np.reshape(-1).astype(np.uint8))).to(device, non_blocking=True)
+
     def plan_masks(self, cmask, smask, content_shape, style_shape, device):
-        """Everything `_transfer_seg` derives from the label maps alone (models/cWCT.py:72-76,166-189): validated /
-        resized uint8 maps on the device and the list of valid labels per sample.  A video loop whose masks do not
-        change builds this once (the reference redoes the host histograms and uploads for every frame)."""
+        """Device-side label plan per sample (numpy label maps as the reference hands them over, or uint8 device tensors).
+        A video loop whose masks do not change builds this once; one whose masks change per frame pays two small
+        histogram kernels per frame and no host work beyond the upload."""
         B, N, cH, cW = content_shape
         _, _, sH, sW = style_shape
+        if N not in (32, 64, 128):
+            raise NotImplementedError("the single-pass masked transfer needs N in (32, 64, 128)")
+        L = _lib.lib()
         plan = MaskPlan()
-        for b in range(B):
-            cm_np, sm_np = np.asarray(cmask[b]), np.asarray(smask[b])
-            if self.resize_masks:
-                if cm_np.shape != (cH, cW):
-                    cm_np = self.resize(np.ascontiguousarray(cm_np.astype(np.uint8)), cH, cW)
-                if sm_np.shape != (sH, sW):
-                    sm_np = self.resize(np.ascontiguousarray(sm_np.astype(np.uint8)), sH, sW)
-            if cm_np.size != cH * cW or sm_np.size != sH * sW:
-                raise ValueError("masks must have the feature resolution "
-                                 f"(content {cm_np.shape} vs {(cH, cW)}, style {sm_np.shape} vs {(sH, sW)})")
-            if cm_np.max() > 255 or sm_np.max() > 255 or cm_np.min() < 0 or sm_np.min() < 0:
-                raise ValueError("labels must be in [0, 255]")
-            label_set, label_indicator = self.compute_label_info(cm_np, sm_np)
-            plan.cm.append(torch.from_numpy(np.ascontiguousarray(cm_np.reshape(-1).astype(np.uint8))).to(device))
-            plan.sm.append(torch.from_numpy(np.ascontiguousarray(sm_np.reshape(-1).astype(np.uint8))).to(device))
-            plan.labels.append([int(l) for l in label_set if label_indicator[l]])
         plan.shapes = (tuple(content_shape), tuple(style_shape))
+        plan.max_slots = 0                # 0 = unknown (launches cover all 32 slots); learn_slots() tightens it
+        plan.tables = []
+        for b in range(B):
+            cm = self._mask_to_device(cmask[b], (cH, cW), device, "content")
+            sm = self._mask_to_device(smask[b], (sH, sW), device, "style")
+            tab = torch.empty(2344, dtype=torch.uint8, device=device)
+            with torch.cuda.device(device):
+                _lib.check(L.vst_label_plan(_ptr(cm), cm.numel(), _ptr(sm), sm.numel(), _ptr(tab), _stream_ptr()), "vst_label_plan")
+            plan.cm.append(cm)
+            plan.sm.append(sm)
+            plan.tables.append(tab)
         return plan
 
+    @staticmethod
+    def plan_info(plan, b=0):
+        """(labels with a slot, overflow flag) of sample b — synchronises; for tests and diagnostics."""
+        raw = plan.tables[b].cpu().numpy()
+        n, over = int(raw[:4].view(np.int32)[0]), int(raw[4:8].view(np.int32)[0])
+        return [int(v) for v in raw[8 + 2048 + 256: 8 + 2048 + 256 + n]], bool(over)
+
+    def learn_slots(self, plan):
+        """Read the slot counts back once (one synchronisation) so that later launches cover only the slots in use — worth
+        it for a plan that is reused over a clip."""
+        plan.max_slots = max(1, max(len(self.plan_info(plan, b)[0]) for b in range(len(plan.tables))))
+        return plan
+
+    def _stats_labels(self, x2d, mask, table, max_slots):
+        N, Lp = x2d.shape
+        L = _lib.lib()
+        out = torch.empty(self.MAX_SLOTS * (1 + N + N * N), dtype=torch.float64, device=x2d.device)
+        ws = self._workspace(L.vst_cwct_labels_workspace_bytes(N, Lp), x2d.device)
+        with torch.cuda.device(x2d.device):
+            _lib.check(L.vst_cwct_stats_labels(_ptr(x2d), N, Lp, _ptr(mask), _ptr(table), int(max_slots), _ptr(out), _ptr(ws),
+                                               _stream_ptr()), "vst_cwct_stats_labels")
+        return out
+
     def bind_style(self, plan, style_feat):
-        """Per-label statistics of the style code, Cholesky-factored once (the masked counterpart of style_stats):
-        transfer_with_plan then skips the style side for every later frame.  Rebind when the style code changes."""
+        """Per-label statistics of the style code, computed once (the masked counterpart of style_stats): transfer_with_plan
+        then skips the style side for every later frame.  Rebind when the style code changes."""
         B, N = style_feat.shape[:2]
         if tuple(style_feat.shape) != plan.shapes[1]:
             raise ValueError(f"plan was made for a style code of shape {plan.shapes[1]}, got {tuple(style_feat.shape)}")
         s = self._prep(style_feat).reshape(B, N, -1)
-        plan.style = []
-        for b in range(B):
-            per_label = {}
-            for label in plan.labels[b]:
-                st = self.stats(s[b], plan.sm[b], label)
-                info = torch.zeros(1, dtype=torch.int32, device=st.device)
-                with torch.cuda.device(st.device):
-                    _lib.check(_lib.lib().vst_cwct_prefactor(_ptr(st), N, float(self.eps), _ptr(st), _ptr(info), _stream_ptr()),
-                               "vst_cwct_prefactor")
-                per_label[label] = st
-            plan.style.append(per_label)
+        plan.style = [self._stats_labels(s[b], plan.sm[b], plan.tables[b], plan.max_slots) for b in range(B)]
         return plan
 
-    def transfer_with_plan(self, content_feat, style_feat, plan):
+    def transfer_with_plan(self, content_feat, style_feat, plan, inplace=False):
         """transfer(content, style, cmask, smask) with the mask work given as plan_masks(...) (and, after bind_style,
-        the style side too; style_feat may then be None)."""
+        the style side too; style_feat may then be None).  Pixels whose label has no slot keep the content feature."""
         B, N, cH, cW = content_feat.shape
         if tuple(content_feat.shape) != plan.shapes[0]:
             raise ValueError(f"plan was made for a content code of shape {plan.shapes[0]}, got {tuple(content_feat.shape)}")
@@ -263,13 +297,43 @@ class cWCT(nn.Module):
             if style_feat is None or tuple(style_feat.shape) != plan.shapes[1]:
                 raise ValueError("transfer_with_plan needs the style code the plan was made for (or bind_style first)")
             s = self._prep(style_feat).reshape(B, N, -1)
+        out = c if inplace and c.data_ptr() == content_feat.data_ptr() else torch.empty_like(c)
+        L = _lib.lib()
+        ms = int(plan.max_slots)
+        for b in range(B):
+            tab = plan.tables[b]
+            cs = self._stats_labels(c[b], plan.cm[b], tab, ms)
+            ss = plan.style[b] if plan.style is not None else self._stats_labels(s[b], plan.sm[b], tab, ms)
+            affines = torch.empty(self.MAX_SLOTS * (N * N + N), dtype=torch.float32, device=c.device)
+            info = torch.empty(self.MAX_SLOTS * 3, dtype=torch.int32, device=c.device)
+            with torch.cuda.device(c.device):
+                _lib.check(L.vst_cwct_factor_labels(_ptr(cs), _ptr(ss), _ptr(tab), ms, float(self.eps), N, _ptr(affines),
+                                                    _ptr(info), _stream_ptr()), "vst_cwct_factor_labels")
+                _lib.check(L.vst_cwct_apply_labels(_ptr(c[b]), _ptr(out[b]), N, c.shape[2], _ptr(affines), _ptr(plan.cm[b]),
+                                                   _ptr(tab), ms, _stream_ptr()), "vst_cwct_apply_labels")
+            self.last_info = info
+        return out.to(in_dtype).reshape(B, N, cH, cW)
+
+    # ------------------------------------------------------------------ per-label form (N = 16 only)
+    def _transfer_seg_per_label(self, content_feat, style_feat, cmask, smask):
+        B, N, cH, cW = content_feat.shape
+        _, _, sH, sW = style_feat.shape
+        in_dtype = content_feat.dtype
+        c = self._prep(content_feat).reshape(B, N, -1)
+        s = self._prep(style_feat).reshape(B, N, -1)
         out = c.clone()
         for b in range(B):
-            for label in plan.labels[b]:
-                cs = self.stats(c[b], plan.cm[b], label)
-                ss = plan.style[b][label] if plan.style is not None else self.stats(s[b], plan.sm[b], label)
-                affine = self.factor(cs, [ss], [1.0], 0.0, N)
-                self.apply(c[b], affine, out=out[b], mask=plan.cm[b], label=label)
+            cm_np, sm_np = np.asarray(cmask[b]), np.asarray(smask[b])
+            if cm_np.size != cH * cW or sm_np.size != sH * sW:
+                raise ValueError("masks must have the feature resolution")
+            label_set, label_indicator = self.compute_label_info(cm_np, sm_np)
+            cm = torch.from_numpy(np.ascontiguousarray(cm_np.reshape(-1).astype(np.uint8))).to(c.device)
+            sm = torch.from_numpy(np.ascontiguousarray(sm_np.reshape(-1).astype(np.uint8))).to(c.device)
+            for label in label_set:
+                if not label_indicator[label]:
+                    continue
+                affine = self.factor(self.stats(c[b], cm, int(label)), [self.stats(s[b], sm, int(label))], [1.0], 0.0, N)
+                self.apply(c[b], affine, out=out[b], mask=cm, label=int(label))
         return out.to(in_dtype).reshape(B, N, cH, cW)
 
     # ------------------------------------------------------------------ helpers (public by convention)
