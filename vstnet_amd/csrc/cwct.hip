@@ -12,6 +12,9 @@
 #include "common.h"
 
 #define CWCT_MAX_STYLES 8
+#ifndef VST_LBL_ABL
+#define VST_LBL_ABL 0        // timing-only builds of cwct_stats_labels_kernel: 1 = no row sums, 2 = no MFMAs, 4 = no staging
+#endif
 #define CWCT_MAX_TRIES 4096
 
 // ================================================================================================
@@ -977,9 +980,6 @@ __global__ __launch_bounds__(256, NBLK == 1 ? 2 : 1) void cwct_stats_labels_kern
         }
         __syncthreads();
         PREFETCH(half, p0 + 2 * PT);                       // in flight during the row sums and MFMAs below and the whole next tile
-#ifndef VST_LBL_ABL
-#define VST_LBL_ABL 0
-#endif
 #pragma unroll
         for (int k = 0; k < KRES; ++k) {
             if (VST_LBL_ABL & 1) break;
