@@ -70,6 +70,10 @@ def main():
                 line += f"   conv.4 WG: {int(st_[0])} cyc / {int(st_[1]) * 10} ns = {int(st_[0]) / max(int(st_[1]), 1) * 0.1:.2f} GHz"
                 st_ = tmp[0:16].view(torch.int64).cpu()
                 line += f"   conv.1 WG: {int(st_[0])} cyc / {int(st_[1]) * 10} ns = {int(st_[0]) / max(int(st_[1]), 1) * 0.1:.2f} GHz"
+                for nm, buf in (("conv.1", tmp[0:528]), ("conv.7", dst.reshape(-1)[:132].view(torch.uint8))):
+                    v = buf.view(torch.int64).cpu().tolist()
+                    line += f"\n      {nm} total {v[0]} cyc; per stage [loads issued, k=2, k=5, mfma done, dma landed, epilogue done, barrier passed]: " + \
+                            " | ".join(" ".join(str(x) for x in v[2 + 7 * i: 9 + 7 * i]) for i in range(8))
             print(line, flush=True)
     x = synthetic_frames(1, H, W).to(dev)
     for name in args.modes.split(","):

@@ -95,10 +95,11 @@ struct vst_prof_scope {
     ~vst_prof_scope() { if (rec >= 0) vst_prof_close(rec, st); }
 };
 
-// conv3.hip: one 256-channel stride-1 coupling block on the LDS-DMA kernels.  tmp = [h1 | h2 | shadow] (vst_block_tmp_bytes);
-// shadow_valid: tmp's shadow already holds the split planes of src; write_shadow: leave the planes of the new dst there
+// conv3.hip: one 256-channel stride-1 coupling block on the LDS-DMA kernels.  tmp = [h1 | h2 | planes A | planes B]
+// (vst_block_tmp_bytes).  pos = position 0..10 of the block in a pass's run of eleven such blocks (the state then lives in the
+// split planes between the run's ends), or -1 for a block on its own (fp32 state in, fp32 state out).
 int vst3_block256(const vst_block_weights* w, int direction, int precision, float* dst, const float* src, void* tmp,
-                  int shadow_valid, int write_shadow, int B, int H, int W, void* stream);
+                  int pos, int B, int H, int W, void* stream);
 
 // internal (not part of the C ABI): input packing with the constant of forward block 0 folded in
 extern "C" int vst_pack_input_k(const float* x, const uint8_t* x_u8, float* s1, float* s2, int B, int C, int H, int W,

@@ -997,7 +997,7 @@ int vst_profile_end(double* total_ms, int* launches) {
     return VST_OK;
 }
 
-// h1 + h2 (8 floats per pixel) + the split-plane shadow of one state half for the stage-3 kernels of conv3.hip (16)
+// h1 + h2 (8 floats per pixel) + the split planes of both state halves for the stage-3 kernels of conv3.hip (2 x 16)
 int vst_profile_end_table(int* ids, double* ms, int* launches, int cap, int* n_ids) {
     if (!ids || !ms || !launches || !n_ids || cap <= 0) return VST_E_ARG;
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -1022,7 +1022,7 @@ int vst_profile_end_table(int* ids, double* ms, int* launches, int cap, int* n_i
     return VST_OK;
 }
 
-size_t vst_block_tmp_bytes(int B, int H, int W) { return (size_t)B * H * W * 24 * sizeof(float); }
+size_t vst_block_tmp_bytes(int B, int H, int W) { return (size_t)B * H * W * 40 * sizeof(float); }
 
 int vst_block_apply(const vst_block_weights* w, int channel, int stride, int direction, int precision,
                     float* dst, const float* src, void* tmp, int B, int H, int W, void* stream) {
@@ -1038,20 +1038,24 @@ int vst_block_apply(const vst_block_weights* w, int channel, int stride, int dir
     if (channel == 64 && stride == 2) return run_block<64, 2>(w, direction, precision, dst, src, t, B, H, W, st);
     if (channel == 256 && stride == 1) {
         if (precision == VST_PREC_F16X2)
-            return vst3_block256(w, direction, precision, dst, src, tmp, 0, 0, B, H, W, stream);
+#if defined(VST_SP_ABLATE) && (VST_SP_ABLATE & 8)
+            return vst3_block256(w, direction, precision, dst, src, tmp, 5, B, H, W, stream);   // diagnostic build: a mid-run block
+#else
+            return vst3_block256(w, direction, precision, dst, src, tmp, -1, B, H, W, stream);
+#endif
         return run_block<256, 1>(w, direction, precision, dst, src, t, B, H, W, st);
     }
     if (channel == 256 && stride == 2) return run_block<256, 2>(w, direction, precision, dst, src, t, B, H, W, st);
     return VST_E_SHAPE;
 }
 
-size_t vst_pass_workspace_bytes(int B, int H, int W) { return (size_t)B * H * W * (16 + 16 + 24) * sizeof(float); }
+size_t vst_pass_workspace_bytes(int B, int H, int W) { return (size_t)B * H * W * (16 + 16 + 40) * sizeof(float); }
 
 // Images per internal sub-batch: the reversible state + intermediates of a sub-batch (160 B/pixel) should stay in
 // the 256 MiB Infinity Cache between the 96 conv launches of a pass (measured: 8 frames of 1024x1024 in one batch
 // run 27 % slower per frame than one at a time); small images are still batched to fill the chip.
 static int pass_sub_batch(int B, int H, int W) {
-    const size_t per_img = (size_t)H * W * 224;
+    const size_t per_img = (size_t)H * W * 288;
     size_t nb = ((size_t)192 << 20) / per_img;
     if (nb < 1) nb = 1;
     return nb > (size_t)B ? B : (int)nb;
@@ -1074,8 +1078,7 @@ static int revnet_forward_chunk(const vst_net_weights* w, const float* x, const 
     const bool sp = precision == VST_PREC_F16X2;
     for (int k = fold0 ? 1 : 0; k < VST_NUM_BLOCKS; ++k) {
         if (sp && k >= 21)      // block k's conv.7 leaves the split planes of its dst = block k+1's src
-            rc = vst3_block256(&w->blocks[k], +1, precision, s[k & 1], s[1 - (k & 1)], tmp, k > 21, k < VST_NUM_BLOCKS - 1,
-                               B, H, W, stream);
+            rc = vst3_block256(&w->blocks[k], +1, precision, s[k & 1], s[1 - (k & 1)], tmp, k - 21, B, H, W, stream);
         else
             rc = vst_block_apply(&w->blocks[k], kBlockChannel[k], kBlockStride[k], +1, precision, s[k & 1], s[1 - (k & 1)],
                                  tmp, B, H, W, stream);
@@ -1095,8 +1098,8 @@ static int revnet_inverse_chunk(const vst_net_weights* w, const float* z, float*
     const bool sp = precision == VST_PREC_F16X2;
     for (int k = VST_NUM_BLOCKS - 1; k >= 0; --k) {
         if (sp && k >= 21)
-            rc = vst3_block256(&w->blocks[k], -1, precision, s[k & 1], s[1 - (k & 1)], tmp, k < VST_NUM_BLOCKS - 1, k > 21,
-                               B, H, W, stream);
+            rc = vst3_block256(&w->blocks[k], -1, precision, s[k & 1], s[1 - (k & 1)], tmp, VST_NUM_BLOCKS - 1 - k, B, H, W,
+                               stream);
         else
             rc = vst_block_apply(&w->blocks[k], kBlockChannel[k], kBlockStride[k], -1, precision, s[k & 1], s[1 - (k & 1)],
                                  tmp, B, H, W, stream);

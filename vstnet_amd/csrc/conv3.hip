@@ -34,8 +34,11 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 struct SpArgs {
     const unsigned char* in;     // SP planes of the input tensor (image 0)
-    float* state;                // OUT_STATE: fp32 state half that is read-modify-written (ZC layout, level 2)
-    unsigned char* out_sp;       // SP planes written by the epilogue: h1 / h2, or the state's shadow (may be null)
+    float* state;                // OUT_STATE: fp32 state half (ZC layout, level 2): the old values unless old_sp is given, and,
+                                 // if store_f32, where the new values go
+    const unsigned char* old_sp; // OUT_STATE: SP planes that hold the old state values (null: read them from `state`)
+    int store_f32;               // OUT_STATE: write the new state as fp32 too (last writers of a half in a pass; lone blocks)
+    unsigned char* out_sp;       // SP planes written by the epilogue: h1 / h2, or the new state (may be null)
     const unsigned char* wfrag;  // permuted-K fp16 weight fragments
     const float* bias;
     int H, W;                    // quarter-resolution image
@@ -107,6 +110,11 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
     const int tx0 = bx * 16, ty0 = by * C::TH, H = a.H, W = a.W;
 #if VST_SP_ABLATE & 8
     const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* const stamp_lds = (unsigned long long*)(smem + C::LDS_BYTES);     // 40 words past the kernel's own LDS
+    int stamp_n = 0;
+#define SP_STAMP() { if (tid == 0 && stamp_n < 64) stamp_lds[stamp_n] = __builtin_amdgcn_s_memtime() - stamp_t0; ++stamp_n; }
+#else
+#define SP_STAMP()
 #endif
     const unsigned char* const in_img = a.in + (size_t)b * a.in_img_bytes;
     const size_t chunk_bytes = (size_t)128 * H * W;           // 4 channel groups x 2 planes
@@ -161,7 +169,9 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
     const int slot_base = (wave * C::MR) * C::IW + lrow;
     const int oy0 = ty0 + wave * C::MR, ox = tx0 + lrow;
     const bool full_tile = ty0 + C::TH <= H && tx0 + 16 <= W;
-    float* const st_img = OUT_STATE ? a.state + (size_t)b * a.state_img_floats : nullptr;
+    float* const st_img = OUT_STATE && a.state ? a.state + (size_t)b * a.state_img_floats : nullptr;
+    const unsigned char* const old_img = OUT_STATE && a.old_sp ? a.old_sp + (size_t)b * a.out_img_bytes : nullptr;
+    const bool store_f32 = OUT_STATE && a.store_f32;
     unsigned char* const sp_img = a.out_sp ? a.out_sp + (size_t)b * a.out_img_bytes : nullptr;
 
     struct Frags { f16x8 w[4], xh[C::MR], xl[C::MR]; };
@@ -177,29 +187,74 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
         }
     };
 
+    // Epilogue of a 64-channel output slice, in two halves: `finish` turns the accumulators into the slice's results
+    // (res = old + sign * (acc + bias), or ReLU(acc + bias)) right after the slice's last MFMA; the stores (fp32 state and /
+    // or split planes) are DEFERRED into the k-steps of the NEXT stage, one unit per k-step between its MFMAs, so that a
+    // slice boundary costs no store-issue time and no barrier skew.  The last slice flushes its units at once.
+    float4 bias[4], old[C::MR][4];
+    f32x4 res[C::MR][4];
+    bool pending = false;                                  // uniform: res holds a slice whose stores are still to be issued
+    int pend_cot = 0, pend_slot0 = 0;                      // its slice; the k-step slots already used for it
+    // unit u = 0..7: fp32 state store (m = u / 4, n = u % 4);  unit 8 + u2, u2 = 0..3: plane pair (m = u2 / 2, j = u2 % 2)
+#define STORE_UNIT(u_)                                                                                                        \
+    {                                                                                                                         \
+        if ((u_) < 8) {                                                                                                       \
+            const int m_ = (u_) / 4, n_ = (u_) % 4, oy_ = oy0 + m_;                                                           \
+            if (store_f32 && (full_tile || (oy_ < H && ox < W)))                                                              \
+                *(float4*)(st_img + ((size_t)oy_ * W + ox) * 256 + pend_cot * 64 + n_ * 16 + 4 * kg) =                        \
+                    make_float4(res[m_][n_][0], res[m_][n_][1], res[m_][n_][2], res[m_][n_][3]);                              \
+        } else {                                                                                                              \
+            const int m_ = ((u_) - 8) / 2, j_ = ((u_) - 8) % 2, oy_ = oy0 + m_;                                               \
+            if (sp_img && (full_tile || (oy_ < H && ox < W))) {                                                               \
+                const float f8_[8] = {res[m_][2 * j_][0], res[m_][2 * j_][1], res[m_][2 * j_][2], res[m_][2 * j_][3],        \
+                                      res[m_][2 * j_ + 1][0], res[m_][2 * j_ + 1][1], res[m_][2 * j_ + 1][2],                 \
+                                      res[m_][2 * j_ + 1][3]};                                                                \
+                u32x4 hi_, lo_;                                                                                               \
+                split8_sp(f8_, hi_, lo_);                                                                                     \
+                const int cig_ = pend_cot * 8 + j_ * 4 + kg;                                                                  \
+                *(u32x4*)(sp_img + sp_offset(cig_, 0, oy_, ox, H, W)) = hi_;                                                  \
+                *(u32x4*)(sp_img + sp_offset(cig_, 1, oy_, ox, H, W)) = lo_;                                                  \
+            }                                                                                                                 \
+        }                                                                                                                     \
+    }
+
 #pragma unroll 1
     for (int q = 0; q < C::Q; ++q) {
         const int cot = q / C::NCHUNK, chunk = q - cot * C::NCHUNK;
         const bool slice_end = chunk == C::NCHUNK - 1;
-        // ---- a slice's last stage: its bias and old state values are fetched first; they are a whole stage old at the
-        //      wait in front of the epilogue ---------------------------------------------------------------------------
-        float4 bias[4], old[C::MR][4];
-        if (slice_end) {
+        // ---- one stage before a slice's last (so that they are two stages old when used): its bias and old state values ------
+        if (chunk == C::NCHUNK - 2) {
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int n = 0; n < 4; ++n) bias[n] = *(const float4*)(a.bias + cot * 64 + n * 16 + 4 * kg);
-            if (OUT_STATE) {
+            // (pixels past the image edge read a clamped, valid address and are never stored: no per-load predicate, which
+            //  would make the compiler branch around every load and wait for each one)
+            const int oxc = ox < W ? ox : W - 1;
+            if (OUT_STATE && old_img == nullptr) {
 #pragma unroll
                 for (int m = 0; m < C::MR; ++m)
 #pragma unroll
                     for (int n = 0; n < 4; ++n) {
-                        const bool ok = full_tile || (oy0 + m < H && ox < W);
-                        old[m][n] = ok ? *(const float4*)(st_img + ((size_t)(oy0 + m) * W + ox) * 256 + cot * 64 + n * 16 + 4 * kg)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const int oyc = oy0 + m < H ? oy0 + m : H - 1;
+                        old[m][n] = *(const float4*)(st_img + ((size_t)oyc * W + oxc) * 256 + cot * 64 + n * 16 + 4 * kg);
+                    }
+            } else if (OUT_STATE) {
+                // inside a pass's run of these blocks the state lives in its split planes only: old = hi + lo
+#pragma unroll
+                for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int oyc = oy0 + m < H ? oy0 + m : H - 1;
+                        const int cig = cot * 8 + j * 4 + kg;
+                        // kept as raw bits (hi in old[m][2j], lo in old[m][2j+1]) and decoded at the slice end: touching the
+                        // values here would be a wait for the loads
+                        old[m][2 * j] = *(const float4*)(old_img + sp_offset(cig, 0, oyc, oxc, H, W));
+                        old[m][2 * j + 1] = *(const float4*)(old_img + sp_offset(cig, 1, oyc, oxc, H, W));
                     }
             }
             asm volatile("" ::: "memory");
         }
+        SP_STAMP();
         const bool issue_w = q + 1 < C::Q;                    // next stage's weights -> the buffer stage q-1 used
         const bool issue_a = q + 1 < C::NCHUNK;               // next chunk's image (first output slice only) -> other image buffer
         const unsigned char* Ab = Abuf + (chunk & 1) * C::A_BUF + (kg * C::NSLOT + slot_base) * 16;
@@ -215,6 +270,11 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
                 if (k < C::WPW && issue_w) ISSUE_W1(q + 1, k);
                 if (k < C::APW && issue_a) ISSUE_A1(q + 1, k);
             }
+            if (pending) {                                   // the previous slice's stores: ONE unit per k-step (the memory pipe
+                constexpr int order[12] = {8, 9, 10, 11, 0, 1, 2, 3, 4, 5, 6, 7};   // takes ~24 B/clk per CU: more would stall the
+                if (pend_slot0 == 0) { STORE_UNIT(order[k]); }                      // waves at issue); plane pairs first
+                else if (k < 3) { STORE_UNIT(order[9 + (k < 3 ? k : 0)]); }
+            }
             __builtin_amdgcn_sched_barrier(0);
             const Frags& f = fr[(VST_SP_ABLATE & 4) ? 0 : (k & 1)];
             if (VST_SP_ABLATE & 2) {
@@ -228,15 +288,29 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[n], f.xl[m], acc[m][n], 0, 0, 0);
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[n], f.xh[m], acc[m][n], 0, 0, 0);
                 }
+            if (k == 2 || k == 5) SP_STAMP();
         }
-        sp_wait_vm<0>();       // this stage's DMA (issued in its first k-steps) and, at a slice end, bias / old state
-        // ---- epilogue of this 64-channel output slice ----------------------------------------------------------------
+        pend_slot0 += 9;
+        if (pend_slot0 >= 12) pending = false;
+        SP_STAMP();
+        sp_wait_vm<0>();       // this stage's DMA and deferred stores (issued in its first k-steps); at a slice end also the bias /
+                               // old state values fetched a stage earlier
+        SP_STAMP();
         if (slice_end) {
+            if (OUT_STATE && old_img != nullptr) {           // old = hi + lo of the lane's 8 channels per (m, j)
 #pragma unroll
-            for (int m = 0; m < C::MR; ++m) {
-                const int oy = oy0 + m;
-                const bool ok = full_tile || (oy < H && ox < W);
-                float r[4][4];
+                for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const f16x8 hi = __builtin_bit_cast(f16x8, old[m][2 * j]), lo = __builtin_bit_cast(f16x8, old[m][2 * j + 1]);
+                        old[m][2 * j] = make_float4((float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1],
+                                                    (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]);
+                        old[m][2 * j + 1] = make_float4((float)hi[4] + (float)lo[4], (float)hi[5] + (float)lo[5],
+                                                        (float)hi[6] + (float)lo[6], (float)hi[7] + (float)lo[7]);
+                    }
+            }
+#pragma unroll
+            for (int m = 0; m < C::MR; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
                     const float bb[4] = {bias[n].x, bias[n].y, bias[n].z, bias[n].w};
@@ -244,39 +318,34 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float v = acc[m][n][e] + bb[e];
-                        r[n][e] = OUT_STATE ? oo[e] + a.sign * v : (v > 0.f ? v : 0.f);
+                        res[m][n][e] = OUT_STATE ? oo[e] + a.sign * v : (v > 0.f ? v : 0.f);
                     }
-                    if (OUT_STATE && ok)
-                        *(float4*)(st_img + ((size_t)oy * W + ox) * 256 + cot * 64 + n * 16 + 4 * kg) =
-                            make_float4(r[n][0], r[n][1], r[n][2], r[n][3]);
                     acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                if (sp_img && ok) {
+            pending = true;
+            pend_cot = cot;
+            pend_slot0 = 0;
+            if (q == C::Q - 1) {                             // nothing left to hide the stores behind
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const float f8[8] = {r[2 * j][0], r[2 * j][1], r[2 * j][2], r[2 * j][3],
-                                             r[2 * j + 1][0], r[2 * j + 1][1], r[2 * j + 1][2], r[2 * j + 1][3]};
-                        u32x4 hi, lo;
-                        split8_sp(f8, hi, lo);
-                        const int cig = cot * 8 + j * 4 + kg;
-                        *(u32x4*)(sp_img + sp_offset(cig, 0, oy, ox, H, W)) = hi;
-                        *(u32x4*)(sp_img + sp_offset(cig, 1, oy, ox, H, W)) = lo;
-                    }
-                }
+                for (int u = 0; u < 12; ++u) STORE_UNIT(u);
             }
             asm volatile("" ::: "memory");
         }
+        SP_STAMP();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        SP_STAMP();
     }
+#undef STORE_UNIT
 #undef ISSUE_A1
 #undef ISSUE_W1
 #if VST_SP_ABLATE & 8
     // diagnostic build only: shader cycles and 100 MHz ticks of one mid-grid workgroup overwrite the head of the output planes
-    if (blockIdx.x == gridDim.x / 2 && tid == 0 && !OUT_STATE) {
-        unsigned long long* d = (unsigned long long*)a.out_sp;
+    if (blockIdx.x == gridDim.x / 2 && tid == 0) {
+        unsigned long long* d = OUT_STATE ? (unsigned long long*)a.state : (unsigned long long*)a.out_sp;
         d[0] = __builtin_amdgcn_s_memtime() - stamp_t0;
         d[1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+        for (int i = 0; i < 64; ++i) d[2 + i] = i < stamp_n ? stamp_lds[i] : 0;
     }
 #endif
 }
@@ -308,29 +377,35 @@ static int launch_sp(SpArgs a, int B, hipStream_t st) {
     using C = SpCfg<CIN, COUT>;
     auto kern = conv_sp_kernel<CIN, COUT, OUT_STATE>;
     static std::atomic<unsigned> attr_done{0};
-    if (int rc = vst_ensure_dynamic_lds((const void*)kern, C::LDS_BYTES, &attr_done)) return rc;
+    if (int rc = vst_ensure_dynamic_lds((const void*)kern, C::LDS_BYTES + ((VST_SP_ABLATE & 8) ? 512 : 0), &attr_done)) return rc;
     a.tiles_x = (a.W + 15) / 16; a.tiles_y = (a.H + C::TH - 1) / C::TH; a.tiles_total = a.tiles_x * a.tiles_y * B;
     vst_prof_scope prof(VST_KERNEL_ID(CIN, COUT, 1), st);
-    kern<<<dim3((a.tiles_total + 7) / 8 * 8), 64 * C::NW, C::LDS_BYTES, st>>>(a);
+    kern<<<dim3((a.tiles_total + 7) / 8 * 8), 64 * C::NW, C::LDS_BYTES + ((VST_SP_ABLATE & 8) ? 512 : 0), st>>>(a);
     VST_RETURN_IF_LAUNCH_FAILED();
     return VST_OK;
 }
 
 int vst3_block256(const vst_block_weights* w, int direction, int precision, float* dst, const float* src, void* tmp,
-                  int shadow_valid, int write_shadow, int B, int H, int W, void* stream) {
+                  int pos, int B, int H, int W, void* stream) {
     if (precision != VST_PREC_F16X2) return VST_E_MODE;
     hipStream_t st = (hipStream_t)stream;
     const int Hq = H >> 2, Wq = W >> 2;
     const size_t mid_bytes = (size_t)Hq * Wq * 64 * 4, state_bytes = (size_t)Hq * Wq * 256 * 4;
     unsigned char* h1 = (unsigned char*)tmp;
     unsigned char* h2 = h1 + (size_t)B * mid_bytes;
-    unsigned char* shadow = h2 + (size_t)B * mid_bytes;
-    if (!shadow_valid) {
+    // two split-plane buffers: inside a pass's run of 256-channel blocks the state lives ONLY there (position pos = 0..10 of the
+    // run; pos < 0 = a block on its own).  A block's src planes are the buffer its predecessor wrote, its dst planes the other.
+    unsigned char* spbuf[2] = {h2 + (size_t)B * mid_bytes, h2 + (size_t)B * mid_bytes + (size_t)B * state_bytes};
+    const bool alone = pos < 0;
+    const int p = alone ? 0 : pos;
+    unsigned char* sp_src = spbuf[p & 1];
+    unsigned char* sp_dst = spbuf[(p & 1) ^ 1];
+    if (p == 0) {                  // first block of the run: the planes of its src come from the fp32 state
         const size_t total = (size_t)B * 32 * Hq * Wq;
         size_t blocks = (total + 255) / 256;
         if (blocks > 16384) blocks = 16384;
         vst_prof_scope prof(VST_KERNEL_PRESPLIT, st);
-        presplit_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(src, shadow, B, Hq, Wq);
+        presplit_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(src, sp_src, B, Hq, Wq);
         VST_RETURN_IF_LAUNCH_FAILED();
     }
     SpArgs a{};
@@ -339,8 +414,8 @@ int vst3_block256(const vst_block_weights* w, int direction, int precision, floa
         const PackedConvLayout L = packed_conv_layout(cout, cin);
         return (const unsigned char*)c.packed + L.f32_bytes + 2 * L.frag_bytes;
     };
-    // conv.1: shadow(src) -> h1
-    a.in = shadow; a.in_img_bytes = state_bytes; a.out_sp = h1; a.out_img_bytes = mid_bytes; a.state = nullptr;
+    // conv.1: planes(src) -> h1
+    a.in = sp_src; a.in_img_bytes = state_bytes; a.out_sp = h1; a.out_img_bytes = mid_bytes; a.state = nullptr;
     a.wfrag = frag(w->conv[0], 64, 256); a.bias = w->conv[0].bias; a.sign = 0.f;
     int rc = launch_sp<256, 64, false>(a, B, st);
     if (rc) return rc;
@@ -349,8 +424,14 @@ int vst3_block256(const vst_block_weights* w, int direction, int precision, floa
     a.wfrag = frag(w->conv[1], 64, 64); a.bias = w->conv[1].bias;
     rc = launch_sp<64, 64, false>(a, B, st);
     if (rc) return rc;
-    // conv.7: h2 -> dst += sign * (.), shadow(dst) for the next block's conv.1
-    a.in = h2; a.out_sp = write_shadow ? shadow : nullptr; a.out_img_bytes = state_bytes; a.state = dst;
+    // conv.7: h2 -> dst += sign * (.).  The old dst values: fp32 for the first two blocks of a run (each half's first update),
+    // afterwards the planes block pos-2 wrote (= this block's dst buffer: read before written, same lane).  The new values go to
+    // the planes (the next block's src / the block after's old values) except for the run's last block, and to the fp32 state
+    // for the last writer of each half (pos >= 9) and for a block on its own.
+    a.in = h2; a.out_img_bytes = state_bytes; a.state = dst;
+    a.old_sp = (!alone && p >= 2) ? sp_dst : nullptr;
+    a.store_f32 = alone || p >= 9;
+    a.out_sp = (!alone && p < 10) ? sp_dst : nullptr;
     a.wfrag = frag(w->conv[2], 256, 64); a.bias = w->conv[2].bias;
     a.sign = direction > 0 ? 1.f : -1.f;
     return launch_sp<64, 256, true>(a, B, st);
