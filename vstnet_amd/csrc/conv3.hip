@@ -64,9 +64,10 @@ __device__ __forceinline__ void glds16(const unsigned char* g, unsigned char* ld
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
-// byte offset of (8-channel group, plane, y, x) in an SP tensor of an HxW image
-__device__ __forceinline__ size_t sp_offset(int cig, int plane, int y, int x, int H, int W) {
-    return ((((size_t)cig * 2 + plane) * H + y) * W + x) * 16;
+// byte offset of (8-channel group, plane, y, x) in an SP tensor of an HxW image (32 bits: one image's planes are at most
+// 4 * 256 * H * W bytes = 1 GiB at the 4096 x 4096 frame's quarter resolution; the image index goes into the 64-bit base)
+__device__ __forceinline__ unsigned sp_offset(int cig, int plane, int y, int x, int H, int W) {
+    return ((((unsigned)cig * 2 + plane) * H + y) * W + x) * 16u;
 }
 
 template <int N> __device__ __forceinline__ void sp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
         if ((u_) < 8) {                                                                                                       \
             const int m_ = (u_) / 4, n_ = (u_) % 4, oy_ = oy0 + m_;                                                           \
             if (store_f32 && (full_tile || (oy_ < H && ox < W)))                                                              \
-                *(float4*)(st_img + ((size_t)oy_ * W + ox) * 256 + pend_cot * 64 + n_ * 16 + 4 * kg) =                        \
+                *(float4*)(st_img + (((unsigned)oy_ * W + ox) * 256u + pend_cot * 64 + n_ * 16 + 4 * kg)) =                   \
                     make_float4(res[m_][n_][0], res[m_][n_][1], res[m_][n_][2], res[m_][n_][3]);                              \
         } else {                                                                                                              \
             const int m_ = ((u_) - 8) / 2, j_ = ((u_) - 8) % 2, oy_ = oy0 + m_;                                               \
@@ -223,10 +224,12 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
         const int cot = q / C::NCHUNK, chunk = q - cot * C::NCHUNK;
         const bool slice_end = chunk == C::NCHUNK - 1;
         // ---- one stage before a slice's last (so that they are two stages old when used): its bias and old state values ------
-        if (chunk == C::NCHUNK - 2) {
-            asm volatile("" ::: "memory");
+        if (slice_end) {                                      // (the bias: a few cached bytes, one stage ahead is plenty)
 #pragma unroll
             for (int n = 0; n < 4; ++n) bias[n] = *(const float4*)(a.bias + cot * 64 + n * 16 + 4 * kg);
+        }
+        if (chunk == C::NCHUNK - 2) {
+            asm volatile("" ::: "memory");
             // (pixels past the image edge read a clamped, valid address and are never stored: no per-load predicate, which
             //  would make the compiler branch around every load and wait for each one)
             const int oxc = ox < W ? ox : W - 1;
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
 #pragma unroll
                     for (int n = 0; n < 4; ++n) {
                         const int oyc = oy0 + m < H ? oy0 + m : H - 1;
-                        old[m][n] = *(const float4*)(st_img + ((size_t)oyc * W + oxc) * 256 + cot * 64 + n * 16 + 4 * kg);
+                        old[m][n] = *(const float4*)(st_img + (((unsigned)oyc * W + oxc) * 256u + cot * 64 + n * 16 + 4 * kg));
                     }
             } else if (OUT_STATE) {
                 // inside a pass's run of these blocks the state lives in its split planes only: old = hi + lo

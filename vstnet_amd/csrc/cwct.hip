@@ -446,15 +446,26 @@ __device__ int fac_factor(const double* stats, float eps, int ti, int tj, float 
 }
 
 template <int BLK>
-__global__ __launch_bounds__(256) void cwct_factor_kernel(FactorArgs a) {
+__global__ __launch_bounds__(256) void cwct_factor_kernel(const FactorArgs args) {
     constexpr int N = 16 * BLK;
-    if (a.n_slots != nullptr) {
-        if ((int)blockIdx.x >= *a.n_slots) return;
-        a.content += blockIdx.x * a.content_stride;
-        for (int s = 0; s < a.n_styles; ++s) a.styles[s] += blockIdx.x * a.style_stride;
-        a.affine += blockIdx.x * a.affine_stride;
-        a.info += blockIdx.x * a.info_stride;
+    // (the per-slot view is built from scalars: indexing / modifying the kernel-argument struct itself would move it to scratch)
+    size_t slot = 0;
+    if (args.n_slots != nullptr) {
+        if ((int)blockIdx.x >= *args.n_slots) return;
+        slot = blockIdx.x;
     }
+    struct {
+        const double* content;
+        const double* const* styles_base;
+        size_t style_off;
+        const float* alphas;
+        int n_styles;
+        float alpha_c, eps;
+        float* affine;
+        int* info;
+        __device__ const double* style(int s) const { return styles_base[s] + style_off; }
+    } a = {args.content + slot * args.content_stride, args.styles, slot * args.style_stride, args.alphas, args.n_styles,
+           args.alpha_c, args.eps, args.affine + slot * args.affine_stride, args.info + slot * args.info_stride};
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
     float* Lmat = (float*)fsm;             // N*N   Lc, row-major
     float* col = Lmat + N * N;             // 2*N   column broadcast of the Cholesky (look-ahead double buffer)
@@ -471,12 +482,12 @@ __global__ __launch_bounds__(256) void cwct_factor_kernel(FactorArgs a) {
         for (int b = 0; b < BLK; ++b) m[a2][b] = 0.f;
     }
     for (int s = 0; s < a.n_styles; ++s) {
-        const int tries = fac_factor<BLK>(a.styles[s], a.eps, ti, tj, r, col, s_piv, s_flag, a.info[2 + s]);
+        const int tries = fac_factor<BLK>(a.style(s), a.eps, ti, tj, r, col, s_piv, s_flag, a.info[2 + s]);
         if (tid == 0) a.info[2 + s] = tries;      // (every thread read its minimum before the first barrier of fac_chol)
         const float al = a.alphas[s];
 #pragma unroll
         for (int a2 = 0; a2 < BLK; ++a2) {
-            mixmu[a2] += (double)(float)a.styles[s][1 + ti + 16 * a2] * (double)al;
+            mixmu[a2] += (double)(float)a.style(s)[1 + ti + 16 * a2] * (double)al;
 #pragma unroll
             for (int b = 0; b < BLK; ++b) m[a2][b] += r[a2][b] * al;
         }
@@ -800,7 +811,7 @@ static int launch_apply(const float* x, float* y, long L, const float* affine, c
     if (!exact && N >= VST_APPLY_SPLIT_MIN_N && mask == nullptr && (L % 64) == 0 && (((uintptr_t)x | (uintptr_t)y) % 16) == 0)
         return launch_apply_split<(N >= 32 ? N : 32)>(x, y, L, affine, st);
     if (N >= 32) {                                           // matrix-core path (needs vector-aligned rows)
-        constexpr int PXM = N == 32 ? 4 : 2;
+        constexpr int PXM = N == 32 ? 4 : (N == 64 ? 2 : 1);    // (N = 128 with two pixel sets needs 512 VGPRs and spills)
         if ((L % PXM) == 0 && L >= PXM && (((uintptr_t)x | (uintptr_t)y) % (4 * PXM)) == 0)
             return launch_apply_mfma<(N >= 32 ? N / 32 : 1), PXM>(x, y, L, affine, mask, label, st);
     }
