@@ -163,6 +163,8 @@ int vst_cwct_apply_prec(const float* x, float* y, int N, long L, const float* af
  *                         stats = double[32][1 + N + N*N].  N in {32, 64, 128}.  workspace: vst_cwct_labels_workspace_bytes.
  * vst_cwct_factor_labels: one workgroup per slot: affines[slot] = {T, t0} of (content slot, style slot); info = int[32][3].
  * vst_cwct_apply_labels : y[:,p] = T[slot(p)] x[:,p] + t0[slot(p)], y = x where the label has no slot; one pass (y may alias x).
+ *                         precision VST_PREC_FP32: exact-fp32 MFMA (one sweep per slot present in a pixel group); otherwise,
+ *                         when L % 64 == 0, bf16 MFMA with split operands (~1.5e-5): HBM-bound however the labels are mixed.
  * max_slots (1..32, 0 = 32) bounds the slots the launches cover when the host knows it (e.g. a plan reused over a clip);
  * nothing here synchronises with the host. */
 #define VST_LABEL_PLAN_BYTES 2344
@@ -173,7 +175,7 @@ int vst_cwct_stats_labels(const float* x, int N, long L, const uint8_t* mask, co
 int vst_cwct_factor_labels(const double* content_stats, const double* style_stats, const void* plan, int max_slots,
                            float eps, int N, float* affines, int* info, void* stream);
 int vst_cwct_apply_labels(const float* x, float* y, int N, long L, const float* affines, const uint8_t* mask,
-                          const void* plan, int max_slots, void* stream);
+                          const void* plan, int max_slots, int precision, void* stream);
 
 /* Turns a statistics record into a "prefactored" one ({-(n+1), mean, chol(cov) with jitter retries}); a style that
  * is reused over many frames (video_transfer.py re-factors it per frame, :195-203) then costs no Cholesky in

@@ -121,7 +121,7 @@ def lib() -> C.CDLL:
         "vst_cwct_labels_workspace_bytes": (sz, [i, lg]),
         "vst_cwct_stats_labels": (i, [vp, i, lg, vp, vp, i, vp, vp, vp]),
         "vst_cwct_factor_labels": (i, [vp, vp, vp, i, f, i, vp, vp, vp]),
-        "vst_cwct_apply_labels": (i, [vp, vp, i, lg, vp, vp, vp, i, vp]),
+        "vst_cwct_apply_labels": (i, [vp, vp, i, lg, vp, vp, vp, i, i, vp]),
         "vst_profile_begin": (i, [i, i]),
         "vst_profile_end": (i, [C.POINTER(C.c_double), C.POINTER(i)]),
         "vst_profile_end_table": (i, [C.POINTER(i), C.POINTER(C.c_double), C.POINTER(i), i, C.POINTER(i)]),

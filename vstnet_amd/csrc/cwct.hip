@@ -266,6 +266,7 @@ __global__ __launch_bounds__(256) void cwct_stats_mean_kernel(const float* __res
     partial += (size_t)blockIdx.y * cwct_partial_stride(N);
     stats += (size_t)(slot0 + blockIdx.y) * (1 + N + (size_t)N * N);
     double acc = 0.0, nt = 0.0;
+#pragma unroll 4                                         // independent records: keep several L2 round trips in flight per lane
     for (int g = gl; g < G; g += 16) {
         const float* rec = partial + (size_t)g * PS;
         const double n = rec[0];
@@ -295,15 +296,15 @@ __global__ __launch_bounds__(256) void cwct_stats_cov_kernel(const float* __rest
     stats += (size_t)(slot0 + blockIdx.y) * (1 + N + (size_t)N * N);
     const double mu_i = stats[1 + i], mu_j = stats[1 + j];
     double m2 = 0.0;
+#pragma unroll 4                                         // independent records: loads first (no branch around them), then the arithmetic
     for (int g = gl; g < G; g += 16) {
         const float* rec = partial + (size_t)g * PS;
-        const double n = rec[0];
-        if (n > 0.0) {
-            const double ai = rec[4 + N + i], aj = rec[4 + N + j];
-            const double di = (double)rec[4 + i] + ai / n - mu_i;
-            const double dj = (double)rec[4 + j] + aj / n - mu_j;
-            m2 += (double)rec[4 + 2 * N + e] - ai * aj / n + n * di * dj;
-        }
+        const float nf = rec[0], aif = rec[4 + N + i], ajf = rec[4 + N + j], si = rec[4 + i], sj = rec[4 + j], q = rec[4 + 2 * N + e];
+        const double n = nf, ai = aif, aj = ajf;
+        const double rn = nf > 0.f ? 1.0 / n : 0.0;
+        const double di = (double)si + ai * rn - mu_i;
+        const double dj = (double)sj + aj * rn - mu_j;
+        m2 += nf > 0.f ? (double)q - ai * aj * rn + n * di * dj : 0.0;
     }
     sm2[gl][el] = m2;
     __syncthreads();
@@ -873,27 +874,26 @@ __global__ __launch_bounds__(256) void label_plan_kernel(LabelPlan* plan) {
 }
 
 // Statistics of KRES label slots [slot0, slot0 + KRES) in one pass over x: like cwct_stats_mfma_kernel, but the 64 pixels of
-// a tile are staged into LDS SORTED by slot (stable; each slot's run padded to an even length with a zero column), so each
+// a tile are staged into LDS SORTED by slot (stable; each slot's run padded to a multiple of 4 with zero columns), so each
 // slot's X X^T runs over its own pixels only: about one tile's worth of MFMAs per tile however the labels are mixed.
 // Every wave sorts for itself (lane = pixel: ballots and popcounts, destinations handed to the staging lanes by shuffles),
-// so the tile costs the same two barriers as the unmasked kernel.
-// For N = 32 the four waves split the work 2 x 2: by slot half (KW = KRES / 2 accumulators per wave instead of KRES) and by
-// pixel-pair parity — 8 resident slots at 2-3 workgroups per CU.
+// so the tile costs the same two barriers as the unmasked kernel.  The products run on v_mfma_f32_16x16x4_f32 (exact fp32):
+// the N x N covariance is (N/16)^2 blocks of 16 x 16, wave w owns blocks w, w + 4, ... for ALL resident slots and all of
+// the tile's pixels (4 accumulator registers per block and slot), so nothing is combined across waves at the end.
 template <int NBLK, int KRES>
-__global__ __launch_bounds__(256, NBLK == 1 ? 2 : 1) void cwct_stats_labels_kernel(const float* __restrict__ x, long L,
-                                                                   const uint8_t* __restrict__ mask,
-                                                                   const LabelPlan* __restrict__ plan, int slot0,
-                                                                   float* __restrict__ partial, int px_per_wg) {
-    constexpr int N = 32 * NBLK, PT = 64, LD = PT + KRES + 1, PG = 4 / NBLK;
+__global__ __launch_bounds__(256, NBLK == 1 ? 3 : 1) void cwct_stats_labels_kernel(const float* __restrict__ x, long L,
+                                                                                   const uint8_t* __restrict__ mask,
+                                                                                   const LabelPlan* __restrict__ plan, int slot0,
+                                                                                   float* __restrict__ partial, int px_per_wg) {
+    constexpr int N = 32 * NBLK, PT = 64, LD = PT + 3 * KRES + 1;
     constexpr int NV = N * PT / 4 / 256;                  // float4 groups per thread and tile
     constexpr int TPC = 256 / N, SPAN = TPC;               // row sums: TPC threads per channel, each takes every TPC-th column
-    constexpr int LS = NBLK == 1 ? 2 : 1, KW = KRES / LS, PGE = PG / LS;   // slot split / slots per wave / pixel-pair groups
+    constexpr int NB16 = N / 16, BPW = NB16 * NB16 / 4;    // 16 x 16 blocks per side / per wave
     __shared__ float xs[N * LD];
     __shared__ float sh[N];
     __shared__ unsigned char lut[256];
     if (slot0 >= plan->n_slots) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rb = wave % NBLK, pgw = wave / NBLK, lh = pgw % LS, pg = pgw / LS;
     const long p_begin = (long)blockIdx.x * px_per_wg;
     long p_end = p_begin + px_per_wg;
     if (p_end > L) p_end = L;
@@ -901,7 +901,7 @@ __global__ __launch_bounds__(256, NBLK == 1 ? 2 : 1) void cwct_stats_labels_kern
     lut[tid] = plan->lut[tid];
     __syncthreads();
 
-    // two tiles in flight per workgroup (the kernel runs at 1-2 workgroups per CU: it needs the bytes in flight)
+    // two tiles in flight per workgroup
     float4 pvq[2][NV];
     int relq[2];                                           // slot (relative to slot0) of pixel p0 + lane of a prefetched tile, -1 = none
     const bool vec = (L % 4) == 0 && ((uintptr_t)x % 16) == 0;
@@ -930,17 +930,16 @@ __global__ __launch_bounds__(256, NBLK == 1 ? 2 : 1) void cwct_stats_labels_kern
         }                                                                                           \
     }
 
-    f32x16 acc[KW][NBLK];                                  // slots lh * KW + kk of this wave
+    f32x4 acc[KRES][BPW];
 #pragma unroll
-    for (int k = 0; k < KW; ++k)
+    for (int k = 0; k < KRES; ++k)
 #pragma unroll
-        for (int b = 0; b < NBLK; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[k][b][r] = 0.f;
+        for (int b = 0; b < BPW; ++b) acc[k][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     float asum[KRES], cnt[KRES];
 #pragma unroll
     for (int k = 0; k < KRES; ++k) { asum[k] = 0.f; cnt[k] = 0.f; }
     const int sc = tid % N, sp = tid / N;                  // row sums: channel and column phase of this thread
+    const int fr = lane & 15, fq = lane >> 4;              // MFMA operand lane: row within the block, pixel within the group of 4
     PREFETCH(0, p_begin);
     PREFETCH(1, p_begin + PT);
 #pragma unroll 1
@@ -951,7 +950,7 @@ __global__ __launch_bounds__(256, NBLK == 1 ? 2 : 1) void cwct_stats_labels_kern
         if (p0 >= p_end) break;
         // ---- stable sort of the tile's pixels by slot, per wave in registers ------------------------------------------
         const int rel = relq[half];
-        int seg_begin[KRES], seg_cnt[KRES], my_begin[KW], my_cnt[KW];
+        int seg_begin[KRES], seg_cnt[KRES];
         int base = 0, mine = -1;
 #pragma unroll
         for (int k = 0; k < KRES; ++k) {
@@ -959,13 +958,7 @@ __global__ __launch_bounds__(256, NBLK == 1 ? 2 : 1) void cwct_stats_labels_kern
             const int c = __popcll(bal);
             if (rel == k) mine = base + __popcll(bal & ((1ull << lane) - 1ull));
             seg_begin[k] = base; seg_cnt[k] = c;
-            if (k < KW || LS == 1) { my_begin[k % KW] = base; my_cnt[k % KW] = c; }
-            else if (lh == 1) { my_begin[k % KW] = base; my_cnt[k % KW] = c; }
-            base += (c + 1) & ~1;
-        }
-        if (LS == 2 && lh == 0) {                          // (the second half's runs were recorded last: restore the first half's)
-#pragma unroll
-            for (int k = 0; k < KW; ++k) { my_begin[k] = seg_begin[k]; my_cnt[k] = seg_cnt[k]; }
+            base += (c + 3) & ~3;
         }
         if (base == 0) {                                   // uniform: no pixel of these slots in the tile
             PREFETCH(half, p0 + 2 * PT);
@@ -984,10 +977,10 @@ __global__ __launch_bounds__(256, NBLK == 1 ? 2 : 1) void cwct_stats_labels_kern
                 if (d >= 0) xs[c * LD + d] = v[q] - s0;
             }
         }
-        if (tid < N) {                                     // zero pad column of every odd-length run
+        if (tid < N) {                                     // zero pad columns of every run whose length is not a multiple of 4
 #pragma unroll
             for (int k = 0; k < KRES; ++k)
-                if (seg_cnt[k] & 1) xs[tid * LD + seg_begin[k] + seg_cnt[k]] = 0.f;
+                for (int j = seg_cnt[k]; j < ((seg_cnt[k] + 3) & ~3); ++j) xs[tid * LD + seg_begin[k] + j] = 0.f;
         }
         __syncthreads();
         PREFETCH(half, p0 + 2 * PT);                       // in flight during the row sums and MFMAs below and the whole next tile
@@ -1009,33 +1002,21 @@ __global__ __launch_bounds__(256, NBLK == 1 ? 2 : 1) void cwct_stats_labels_kern
             asum[k] += sacc;
             cnt[k] += (float)nc;
         }
-        const float* bptr = xs + (lane & 31) * LD + (lane >> 5);
 #pragma unroll
-        for (int k = 0; k < KW; ++k) {
+        for (int k = 0; k < KRES; ++k) {
             if (VST_LBL_ABL & 2) break;
-            const int nb = my_begin[k], npair = (my_cnt[k] + 1) >> 1;
-            // four pixel pairs per round: their fragment reads are issued together (a pair past the run's end reads the
-            // last pair's address and contributes zeros), then the MFMAs
-            for (int t0 = pg; t0 < npair; t0 += 4 * PGE) {
-                float f[4][NBLK];
+            const int nb = seg_begin[k], ng = (seg_cnt[k] + 3) >> 2;    // groups of 4 pixels
+            for (int g = 0; g < ng; ++g) {
+                float f[NB16];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int t = t0 + u * PGE;
-                    const int tc = t < npair ? t : npair - 1;
+                for (int b = 0; b < NB16; ++b) f[b] = xs[(16 * b + fr) * LD + nb + 4 * g + fq];
 #pragma unroll
-                    for (int b = 0; b < NBLK; ++b) {
-                        const float v = bptr[b * 32 * LD + nb + 2 * tc];
-                        f[u][b] = t < npair ? v : 0.f;
-                    }
-                }
+                for (int b = 0; b < BPW; ++b) {
+                    const int blk = wave + 4 * b, bi = blk / NB16, bj = blk % NB16;     // wave-uniform block coordinates
+                    float fa = f[0], fb = f[0];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    float fa = f[u][0];
-#pragma unroll
-                    for (int b = 1; b < NBLK; ++b) fa = rb == b ? f[u][b] : fa;
-#pragma unroll
-                    for (int b = 0; b < NBLK; ++b)
-                        acc[k][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, f[u][b], acc[k][b], 0, 0, 0);
+                    for (int t = 1; t < NB16; ++t) { fa = bi == t ? f[t] : fa; fb = bj == t ? f[t] : fb; }
+                    acc[k][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, acc[k][b], 0, 0, 0);
                 }
             }
         }
@@ -1059,37 +1040,13 @@ __global__ __launch_bounds__(256, NBLK == 1 ? 2 : 1) void cwct_stats_labels_kern
         }
         if (tid == 0) rec[0] = cnt[k];
         for (int c = tid; c < N; c += 256) rec[4 + c] = sh[c];
-    }
-    float* const xch = xs + lh * (NBLK * NBLK * 16 * 64);  // exchange region of this slot half
+        // accumulator layout of the 16x16 MFMA: lane (j = lane % 16, ig = lane / 16) holds rows 4 ig + r, column j
 #pragma unroll
-    for (int k = 0; k < KW; ++k) {
-        float* rec = partial + ((size_t)blockIdx.x * KRES + lh * KW + k) * PS;
-        if (PGE > 1) {
-            for (int round = 1; round < PGE; ++round) {
-                __syncthreads();
-                if (pg == round) {
+        for (int b = 0; b < BPW; ++b) {
+            const int blk = wave + 4 * b, bi = blk / NB16, bj = blk % NB16;
 #pragma unroll
-                    for (int b = 0; b < NBLK; ++b)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) xch[((rb * NBLK + b) * 16 + r) * 64 + lane] = acc[k][b][r];
-                }
-                __syncthreads();
-                if (pg == 0) {
-#pragma unroll
-                    for (int b = 0; b < NBLK; ++b)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[k][b][r] += xch[((rb * NBLK + b) * 16 + r) * 64 + lane];
-                }
-            }
-        }
-        if (pg == 0) {
-#pragma unroll
-            for (int b = 0; b < NBLK; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = b * 32 + (lane & 31);
-                    rec[4 + 2 * N + (size_t)i * N + j] = acc[k][b][r];
-                }
+            for (int r = 0; r < 4; ++r)
+                rec[4 + 2 * N + (size_t)(16 * bi + 4 * fq + r) * N + 16 * bj + fr] = acc[k][b][r];
         }
     }
 }
@@ -1195,7 +1152,132 @@ __global__ __launch_bounds__(256) void cwct_apply_labels_kernel(const float* x, 
     }
 }
 
-template <int N> struct LabelCfg { static constexpr int NBLK = N / 32, KRES = 8 / NBLK, KAPP = N == 128 ? 1 : (N == 64 ? 4 : 8); };
+// The same per-pixel map on the bf16 matrix cores with split operands (cwct_apply_split_kernel's arithmetic, ~1.5e-5):
+// sixteen times the rate of the exact-fp32 MFMA, so one sweep per slot present in a 16*PQ-pixel group costs next to nothing
+// and the pass stays HBM-bound however the labels are mixed.  A pixel's x fragments are split once and zeroed per slot by
+// selects (one pixel = one lane's whole fragment).  Pixels that this pass does not transform are copied (first pass) or left
+// alone (later passes): their lanes re-read x at the output channel positions.  Needs L % (16 PQ) == 0 and 16-byte rows.
+template <int N, int KAPP>
+__global__ __launch_bounds__(256, 2) void cwct_apply_labels_split_kernel(const float* x, float* y, long L,
+                                                                         const float* __restrict__ affines,
+                                                                         const uint8_t* __restrict__ mask,
+                                                                         const LabelPlan* __restrict__ plan, int slot0, long niter) {
+    constexpr int MB = N / 16, KS = N / 32, TF = MB * KS * 64;
+    constexpr int PQ = N >= 128 ? 2 : 4;
+    typedef __attribute__((ext_vector_type(PQ))) float fvec;
+    extern __shared__ __attribute__((aligned(16))) unsigned char asm4_[];
+    uint4* const th = (uint4*)asm4_;                        // [KAPP][MB][KS][4 kg][16 lrow] fragments of 8 bf16
+    uint4* const tl = th + KAPP * TF;
+    float* const t0 = (float*)(tl + KAPP * TF);             // [KAPP][N]
+    __shared__ unsigned char lut[256];
+    const int n_slots = plan->n_slots;
+    if (slot0 > 0 && slot0 >= n_slots) return;
+    const bool first = slot0 == 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int f0 = tid; f0 < KAPP * TF; f0 += 256) {
+        const int k = f0 / TF, f = f0 - k * TF;
+        const int lrow = f & 15, kg = (f >> 4) & 3, ks = (f >> 6) % KS, m = (f >> 6) / KS;
+        bf16x8 h, l;
+        const bool have = slot0 + k < n_slots;
+        const float* src = affines + (size_t)(slot0 + (have ? k : 0)) * ((size_t)N * N + N) + (size_t)(16 * m + lrow) * N + 32 * ks + 8 * kg;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float v = have ? src[i] : 0.f;
+            h[i] = (__bf16)v;
+            l[i] = (__bf16)(v - (float)h[i]);
+        }
+        th[f0] = __builtin_bit_cast(uint4, h);
+        tl[f0] = __builtin_bit_cast(uint4, l);
+    }
+    for (int i = tid; i < KAPP * N; i += 256) {
+        const int k = i / N;
+        t0[i] = slot0 + k < n_slots ? affines[(size_t)(slot0 + k) * ((size_t)N * N + N) + (size_t)N * N + (i - k * N)] : 0.f;
+    }
+    lut[tid] = plan->lut[tid];
+    __syncthreads();
+    const int n16 = lane & 15, kg = lane >> 4;
+    for (long it = (long)blockIdx.x * 4 + wave; it < niter; it += (long)gridDim.x * 4) {
+        const long p = it * (16 * PQ) + PQ * n16;
+        int sl[PQ];                                          // slot relative to slot0, or -1 = not transformed by this pass
+        unsigned present = 0;
+        bool any_other = false, all_mine = true;
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+            const int s2 = lut[mask[p + q]];
+            sl[q] = (s2 != 255 && s2 >= slot0 && s2 < slot0 + KAPP) ? s2 - slot0 : -1;
+            if (sl[q] >= 0) present |= 1u << sl[q];
+            any_other |= sl[q] < 0;
+            all_mine &= sl[q] >= 0;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) present |= (unsigned)__shfl_xor((int)present, o, 64);
+        if (present == 0 && !first) continue;                // uniform: nothing of this pass in the wave's pixels
+        f32x4 acc[PQ][MB];
+#pragma unroll
+        for (int q = 0; q < PQ; ++q)
+#pragma unroll
+            for (int m = 0; m < MB; ++m) acc[q][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (present != 0) {
+#pragma unroll 1
+            for (int ks = 0; ks < KS; ++ks) {
+                fvec v[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = *(const fvec*)(x + (size_t)(32 * ks + 8 * kg + c) * L + p);
+                bf16x8 xh[PQ], xl[PQ];
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+#pragma unroll
+                    for (int q = 0; q < PQ; ++q) {
+                        xh[q][c] = (__bf16)v[c][q];
+                        xl[q][c] = (__bf16)(v[c][q] - (float)xh[q][c]);
+                    }
+                for (int k = 0; k < KAPP; ++k) {
+                    if (!((present >> k) & 1u)) continue;    // uniform
+                    const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                    bf16x8 mh[PQ], ml[PQ];
+#pragma unroll
+                    for (int q = 0; q < PQ; ++q) { mh[q] = sl[q] == k ? xh[q] : zero; ml[q] = sl[q] == k ? xl[q] : zero; }
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) {
+                        const bf16x8 wh = __builtin_bit_cast(bf16x8, th[k * TF + (m * KS + ks) * 64 + kg * 16 + n16]);
+                        const bf16x8 wl = __builtin_bit_cast(bf16x8, tl[k * TF + (m * KS + ks) * 64 + kg * 16 + n16]);
+#pragma unroll
+                        for (int q = 0; q < PQ; ++q) {
+                            acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ml[q], acc[q][m], 0, 0, 0);
+                            acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, mh[q], acc[q][m], 0, 0, 0);
+                            acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, mh[q], acc[q][m], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        // lane (n16, kg) holds output channels 16 m + 4 kg + r of pixels p + q
+        const bool copy_some = first && any_other;            // pixels of no slot / of a later pass: y = x
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 16 * m + 4 * kg + r;
+                fvec o;
+#pragma unroll
+                for (int q = 0; q < PQ; ++q) o[q] = acc[q][m][r] + (sl[q] >= 0 ? t0[sl[q] * N + co] : 0.f);
+                if (copy_some) {
+                    const fvec xin = *(const fvec*)(x + (size_t)co * L + p);
+#pragma unroll
+                    for (int q = 0; q < PQ; ++q) o[q] = sl[q] >= 0 ? o[q] : xin[q];
+                }
+                float* dstp = y + (size_t)co * L + p;
+                if (first || all_mine) *(fvec*)dstp = o;
+                else {
+#pragma unroll
+                    for (int q = 0; q < PQ; ++q) if (sl[q] >= 0) dstp[q] = o[q];
+                }
+            }
+    }
+}
+
+// slots per statistics pass (KRES: 4 accumulator registers per 16x16 block, slot and wave) and per apply pass (KAPP: T tables in LDS)
+template <int N> struct LabelCfg { static constexpr int NBLK = N / 32, KRES = N == 128 ? 1 : 8 / NBLK, KAPP = N == 128 ? 1 : (N == 64 ? 4 : 8); };
 
 
 template <int N>
@@ -1214,6 +1296,25 @@ static int stats_labels(const float* x, long L, const uint8_t* mask, const Label
     return VST_OK;
 }
 
+
+template <int N>
+static int apply_labels_split(const float* x, float* y, long L, const float* affines, const uint8_t* mask, const LabelPlan* plan,
+                              int max_slots, hipStream_t st) {
+    using C = LabelCfg<N>;
+    constexpr int MB = N / 16, KS = N / 32, TF = MB * KS * 64, PQ = N >= 128 ? 2 : 4;
+    const long niter = L / (16 * PQ);
+    long wgs = (niter + 3) / 4;
+    if (wgs > 2048) wgs = 2048;
+    const size_t lds = (size_t)C::KAPP * (2 * TF * 16 + N * sizeof(float));
+    auto kern = cwct_apply_labels_split_kernel<N, C::KAPP>;
+    static std::atomic<unsigned> attr_done{0};
+    if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)lds, &attr_done)) return rc_;
+    for (int slot0 = 0; slot0 < max_slots; slot0 += C::KAPP) {
+        kern<<<dim3((unsigned)wgs), 256, lds, st>>>(x, y, L, affines, mask, plan, slot0, niter);
+        VST_RETURN_IF_LAUNCH_FAILED();
+    }
+    return VST_OK;
+}
 
 template <int N, int PXV>
 static int apply_labels(const float* x, float* y, long L, const float* affines, const uint8_t* mask, const LabelPlan* plan,
@@ -1356,7 +1457,7 @@ int vst_label_plan(const uint8_t* cmask, long Lc, const uint8_t* smask, long Ls,
 size_t vst_cwct_labels_workspace_bytes(int N, long L) {
     int per;
     const int g = cwct_stats_groups(L, &per);
-    const int kres = N >= 32 ? 8 / (N / 32) : 8;
+    const int kres = N == 128 ? 1 : (N >= 32 ? 8 / (N / 32) : 8);
     return (size_t)g * kres * cwct_partial_stride(N) * sizeof(float);
 }
 
@@ -1403,13 +1504,22 @@ int vst_cwct_factor_labels(const double* content_stats, const double* style_stat
 }
 
 int vst_cwct_apply_labels(const float* x, float* y, int N, long L, const float* affines, const uint8_t* mask, const void* plan,
-                          int max_slots, void* stream) {
+                          int max_slots, int precision, void* stream) {
     if (!x || !y || !affines || !mask || !plan || L <= 0) return VST_E_ARG;
-    if (x == y && max_slots > 8) { /* in place is fine: a pass reads a pixel group before it writes it */ }
+    if (precision != VST_PREC_BF16X3 && precision != VST_PREC_FP32 && precision != VST_PREC_F16X2) return VST_E_MODE;
     if (max_slots <= 0 || max_slots > CWCT_MAX_SLOTS) max_slots = CWCT_MAX_SLOTS;
     hipStream_t st = (hipStream_t)stream;
     vst_prof_scope prof(VST_KERNEL_CWCT_APPLY, st);
     const LabelPlan* p = (const LabelPlan*)plan;
+    // (in place is fine in every form: a wave reads its pixel group before it writes it)
+    if (precision != VST_PREC_FP32 && (L % 64) == 0 && (((uintptr_t)x | (uintptr_t)y) % 16) == 0 && ((uintptr_t)mask % 4) == 0) {
+        switch (N) {
+            case 32: return apply_labels_split<32>(x, y, L, affines, mask, p, max_slots, st);
+            case 64: return apply_labels_split<64>(x, y, L, affines, mask, p, max_slots, st);
+            case 128: return apply_labels_split<128>(x, y, L, affines, mask, p, max_slots, st);
+            default: return VST_E_SHAPE;
+        }
+    }
     const bool v4 = (L % 4) == 0 && (((uintptr_t)x | (uintptr_t)y) % 16) == 0;
     const bool v2 = (L % 2) == 0 && (((uintptr_t)x | (uintptr_t)y) % 8) == 0;
     switch (N) {

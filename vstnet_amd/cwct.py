@@ -309,8 +309,9 @@ class cWCT(nn.Module):
             with torch.cuda.device(c.device):
                 _lib.check(L.vst_cwct_factor_labels(_ptr(cs), _ptr(ss), _ptr(tab), ms, float(self.eps), N, _ptr(affines),
                                                     _ptr(info), _stream_ptr()), "vst_cwct_factor_labels")
+                prec = {"fp32": _lib.PREC_FP32, "bf16x3": _lib.PREC_BF16X3, "f16x2": _lib.PREC_F16X2}[self.precision]
                 _lib.check(L.vst_cwct_apply_labels(_ptr(c[b]), _ptr(out[b]), N, c.shape[2], _ptr(affines), _ptr(plan.cm[b]),
-                                                   _ptr(tab), ms, _stream_ptr()), "vst_cwct_apply_labels")
+                                                   _ptr(tab), ms, prec, _stream_ptr()), "vst_cwct_apply_labels")
             self.last_info = info
         return out.to(in_dtype).reshape(B, N, cH, cW)
 
