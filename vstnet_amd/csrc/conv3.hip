@@ -80,12 +80,15 @@ struct SpCfg {
     static constexpr int NSLOT = (NPIX + 15) / 16 * 16;      // multiple of 16: the four k-group planes start 256 B apart mod the 256-B bank row
     static constexpr int A_PLANE = 4 * NSLOT * 16, A_BUF = 2 * A_PLANE;      // [plane][cig][slot][16 B]
     static constexpr int APIECES = A_BUF / 1024;             // DMA pieces (64 lanes x 16 B) per chunk image (42)
-    static constexpr int APW = (APIECES + NW - 1) / NW;      // per wave (6)
-    static constexpr int WPIECES = 36, WPW = (WPIECES + NW - 1) / NW;        // weight pieces per stage / per wave (5)
+    // Only waves 0-3 issue DMA ("loaders"); their SIMD partners 4-7 run nothing but fragment reads and MFMAs, so the matrix
+    // pipe of every SIMD has a wave to draw from while the other one is busy issuing pieces.
+    static constexpr int NLOAD = 4;
+    static constexpr int APW = (APIECES + NLOAD - 1) / NLOAD;                // image pieces per loader wave and chunk (11)
+    static constexpr int WPIECES = 36, WPW = WPIECES / NLOAD;                // weight pieces per stage / per loader wave (9)
     static constexpr int B_BUF = 9 * 4 * 64 * 16;            // [k][kg][co][16 B] = 36864
     static constexpr int LDS_BYTES = 2 * A_BUF + 2 * B_BUF;  // 159744
     static_assert(A_BUF % 1024 == 0 && LDS_BYTES <= 160 * 1024, "LDS budget");
-    static_assert(APW <= 9 && WPW <= 9, "one piece of each kind per k-step");
+    static_assert(APW <= 18 && WPW == 9, "one weight piece and at most two image pieces per k-step");
 };
 
 template <int CIN, int COUT, bool OUT_STATE>
@@ -136,28 +139,26 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
         a_off[u] = (unsigned)sp_offset(pc & 3, pc >> 2, gy, gx, H, W);
         a_dst[u] = i * 1024;
     }
-    unsigned w_off[C::WPW], w_dst[C::WPW];
-#pragma unroll
-    for (int u = 0; u < C::WPW; ++u) {
-        int j = wave * C::WPW + u;
-        j = j > C::WPIECES - 1 ? C::WPIECES - 1 : j;
-        w_off[u] = (unsigned)((j * COUT + lane) * 16);        // j = k*4 + kg
-        w_dst[u] = j * 1024;
-    }
+    const bool loader = wave < C::NLOAD;
+    // weight piece u of loader wave w: j = w * WPW + u (j = k*4 + kg): source (j * COUT + lane) * 16, destination j * 1024
+    const unsigned w_off0 = (unsigned)((wave * C::WPW * COUT + lane) * 16);
     // piece u_ of the image of chunk chunk_ / of the weights of stage q_ (into weight buffer q_ & 1)
 #define ISSUE_A1(chunk_, u_) \
     glds16(in_img + (size_t)(chunk_) * chunk_bytes + a_off[u_], Abuf + ((chunk_) & 1) * C::A_BUF + a_dst[u_])
 #define ISSUE_W1(q_, u_)                                                                                          \
     {                                                                                                            \
         const int cot_ = (q_) / C::NCHUNK, chunk_ = (q_) - cot_ * C::NCHUNK;                                     \
-        glds16(a.wfrag + ((size_t)chunk_ * 36 * COUT + cot_ * 64) * 16 + w_off[u_], Bbuf + ((q_) & 1) * C::B_BUF + w_dst[u_]); \
+        glds16(a.wfrag + ((size_t)chunk_ * 36 * COUT + cot_ * 64) * 16 + w_off0 + (u_) * (COUT * 16),                 \
+               Bbuf + ((q_) & 1) * C::B_BUF + (wave * C::WPW + (u_)) * 1024);                                     \
     }
 
     // ---- prologue: chunk 0 and the weights of stage 0 ----------------------------------------------------------------
+    if (loader) {
 #pragma unroll
-    for (int u = 0; u < C::APW; ++u) ISSUE_A1(0, u);
+        for (int u = 0; u < C::APW; ++u) ISSUE_A1(0, u);
 #pragma unroll
-    for (int u = 0; u < C::WPW; ++u) ISSUE_W1(0, u);
+        for (int u = 0; u < C::WPW; ++u) ISSUE_W1(0, u);
+    }
     sp_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -269,9 +270,12 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
         for (int k = 0; k < 9; ++k) {
             __builtin_amdgcn_sched_barrier(0);
             if (k < 8 && !(VST_SP_ABLATE & 4)) read_frags(fr[(k + 1) & 1], Ab, Bb, k + 1);
-            if (!(VST_SP_ABLATE & 1)) {
-                if (k < C::WPW && issue_w) ISSUE_W1(q + 1, k);
-                if (k < C::APW && issue_a) ISSUE_A1(q + 1, k);
+            if (!(VST_SP_ABLATE & 1) && loader) {
+                if (issue_w) ISSUE_W1(q + 1, k);
+                if (issue_a) {
+                    ISSUE_A1(q + 1, k);
+                    if (9 + k < C::APW) ISSUE_A1(q + 1, 9 + k);
+                }
             }
             if (pending) {                                   // the previous slice's stores: ONE unit per k-step (the memory pipe
                 constexpr int order[12] = {8, 9, 10, 11, 0, 1, 2, 3, 4, 5, 6, 7};   // takes ~24 B/clk per CU: more would stall the
