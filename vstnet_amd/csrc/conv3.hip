@@ -229,33 +229,28 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
 #pragma unroll
             for (int n = 0; n < 4; ++n) bias[n] = *(const float4*)(a.bias + cot * 64 + n * 16 + 4 * kg);
         }
-        if (chunk == C::NCHUNK - 2) {
-            asm volatile("" ::: "memory");
-            // (pixels past the image edge read a clamped, valid address and are never stored: no per-load predicate, which
-            //  would make the compiler branch around every load and wait for each one)
+        // Its old state values too, HERE: at a stage's top no DMA is in flight (an ordinary load issued while LDS-DMA is
+        // pending makes hipcc drain the whole queue first), the previous slice's deferred stores went out a stage ago (both
+        // share one ~24 B/clk pipe), and the values are a whole stage old when the slice ends.  Pixels past the image edge read
+        // a clamped, valid address and are never stored: no per-load predicate (the compiler would branch around every load and
+        // wait for each one).  Plane loads are kept as raw bits (hi in old[m][2j], lo in old[m][2j+1]) and decoded at the slice
+        // end: touching them here would be a wait.
+        if (OUT_STATE && slice_end) {
             const int oxc = ox < W ? ox : W - 1;
-            if (OUT_STATE && old_img == nullptr) {
 #pragma unroll
-                for (int m = 0; m < C::MR; ++m)
+            for (int m = 0; m < C::MR; ++m)
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) {
-                        const int oyc = oy0 + m < H ? oy0 + m : H - 1;
-                        old[m][n] = *(const float4*)(st_img + (((unsigned)oyc * W + oxc) * 256u + cot * 64 + n * 16 + 4 * kg));
-                    }
-            } else if (OUT_STATE) {
-                // inside a pass's run of these blocks the state lives in its split planes only: old = hi + lo
-#pragma unroll
-                for (int m = 0; m < C::MR; ++m)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int oyc = oy0 + m < H ? oy0 + m : H - 1;
+                for (int j = 0; j < 2; ++j) {
+                    const int oyc = oy0 + m < H ? oy0 + m : H - 1;
+                    if (old_img == nullptr) {
+                        old[m][2 * j] = *(const float4*)(st_img + (((unsigned)oyc * W + oxc) * 256u + cot * 64 + (2 * j) * 16 + 4 * kg));
+                        old[m][2 * j + 1] = *(const float4*)(st_img + (((unsigned)oyc * W + oxc) * 256u + cot * 64 + (2 * j + 1) * 16 + 4 * kg));
+                    } else {
                         const int cig = cot * 8 + j * 4 + kg;
-                        // kept as raw bits (hi in old[m][2j], lo in old[m][2j+1]) and decoded at the slice end: touching the
-                        // values here would be a wait for the loads
                         old[m][2 * j] = *(const float4*)(old_img + sp_offset(cig, 0, oyc, oxc, H, W));
                         old[m][2 * j + 1] = *(const float4*)(old_img + sp_offset(cig, 1, oyc, oxc, H, W));
                     }
-            }
+                }
             asm volatile("" ::: "memory");
         }
         SP_STAMP();
