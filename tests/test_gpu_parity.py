@@ -471,8 +471,8 @@ def test_native_runner_matches_python_path(tmp_path):
     from vstnet_amd.export import export_state_dict
     if not os.path.exists(_lib.RUNNER_BIN):
         _lib.build_runner()
-    for mode in ("photo", "art"):
-        net, sd, sp = make_net(mode)
+    for mode, precision in (("photo", "f16x2"), ("art", "f16x2"), ("photo", "bf16x3")):
+        net, sd, sp = make_net(mode, precision)
         hd = 16 if mode == "photo" else 64
         export_state_dict(sd, str(tmp_path / "w.bin"), hd, sp)
         g = torch.Generator().manual_seed(9)
@@ -480,13 +480,14 @@ def test_native_runner_matches_python_path(tmp_path):
         s = torch.randint(0, 256, (1, 32, 48, 3), dtype=torch.uint8, generator=g)
         c.numpy().tofile(tmp_path / "c.rgb"); s.numpy().tofile(tmp_path / "s.rgb")
         r = subprocess.run([_lib.RUNNER_BIN, str(tmp_path / "w.bin"), str(tmp_path / "c.rgb"), "40", "64",
-                            str(tmp_path / "s.rgb"), "32", "48", str(tmp_path / "o.rgb")], capture_output=True, text=True)
+                            str(tmp_path / "s.rgb"), "32", "48", str(tmp_path / "o.rgb")] + ([] if precision == "f16x2" else [precision]),
+                           capture_output=True, text=True)
         assert r.returncode == 0, r.stderr + r.stdout
         got = np.fromfile(tmp_path / "o.rgb", dtype=np.uint8).reshape(40, 64, 3)
-        cw = cWCT()
+        cw = cWCT(precision=precision)
         zc, zs = net.forward_u8(c.cuda()), net.forward_u8(s.cuda())
         ref = net.inverse_u8(cw.transfer_with_stats(zc, cw.style_stats(zs)))[0].cpu().numpy()
-        assert np.array_equal(got, ref), mode
+        assert np.array_equal(got, ref), (mode, precision)
 
 
 def test_lab_luminance_postprocess(L, golden):

@@ -10,6 +10,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -32,7 +33,16 @@ static bool read_file(const char* path, std::vector<uint8_t>& buf) {
 }
 
 int main(int argc, char** argv) {
-    if (argc != 9) { fprintf(stderr, "usage: %s weights.bin content.rgb H W style.rgb Hs Ws out.rgb\n", argv[0]); return 1; }
+    if (argc != 9 && argc != 10) {
+        fprintf(stderr, "usage: %s weights.bin content.rgb H W style.rgb Hs Ws out.rgb [f16x2|bf16x3|fp32]\n", argv[0]);
+        return 1;
+    }
+    int prec = VST_PREC_F16X2;                    // the drop-in classes' default
+    if (argc == 10) {
+        if (!strcmp(argv[9], "bf16x3")) prec = VST_PREC_BF16X3;
+        else if (!strcmp(argv[9], "fp32")) prec = VST_PREC_FP32;
+        else if (strcmp(argv[9], "f16x2")) { fprintf(stderr, "unknown precision %s\n", argv[9]); return 1; }
+    }
     const int H = atoi(argv[3]), W = atoi(argv[4]), Hs = atoi(argv[6]), Ws = atoi(argv[7]);
     std::vector<uint8_t> wfile, content, style;
     if (!read_file(argv[1], wfile) || !read_file(argv[2], content) || !read_file(argv[5], style)) { fprintf(stderr, "cannot read inputs\n"); return 1; }
@@ -88,16 +98,16 @@ int main(int argc, char** argv) {
     HIP_OK(hipMemcpyAsync(d_s, style.data(), style.size(), hipMemcpyHostToDevice, st));
 
     // ---- the hot path ---------------------------------------------------------------------------------------------------
-    VST_CALL(vst_revnet_forward_u8(&net, d_c, z_c, ws, 1, H, W, sp, VST_PREC_BF16X3, st));
-    VST_CALL(vst_revnet_forward_u8(&net, d_s, z_s, ws, 1, Hs, Ws, sp, VST_PREC_BF16X3, st));
+    VST_CALL(vst_revnet_forward_u8(&net, d_c, z_c, ws, 1, H, W, sp, prec, st));
+    VST_CALL(vst_revnet_forward_u8(&net, d_s, z_s, ws, 1, Hs, Ws, sp, prec, st));
     VST_CALL(vst_cwct_stats(z_s, N, Ls, nullptr, 0, st_s, cws, st));
     VST_CALL(vst_cwct_prefactor(st_s, N, 2e-5f, st_s, info, st));
     VST_CALL(vst_cwct_stats(z_c, N, L, nullptr, 0, st_c, cws, st));
     const double* styles[1] = {st_s};
     const float alphas[1] = {1.f};
     VST_CALL(vst_cwct_factor(st_c, styles, alphas, 1, 0.f, 2e-5f, N, affine, info, st));
-    VST_CALL(vst_cwct_apply(z_c, z_cs, N, L, affine, nullptr, 0, st));
-    VST_CALL(vst_revnet_inverse_u8(&net, z_cs, d_out, ws, 1, H, W, sp, VST_PREC_BF16X3, st));
+    VST_CALL(vst_cwct_apply_prec(z_c, z_cs, N, L, affine, nullptr, 0, prec, st));
+    VST_CALL(vst_revnet_inverse_u8(&net, z_cs, d_out, ws, 1, H, W, sp, prec, st));
 
     std::vector<uint8_t> out(content.size());
     HIP_OK(hipMemcpyAsync(out.data(), d_out, out.size(), hipMemcpyDeviceToHost, st));
