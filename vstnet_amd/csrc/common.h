@@ -12,6 +12,8 @@
     } while (0)
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -45,6 +47,29 @@ __device__ __forceinline__ int reflect_clamp(int v, int n) {
     v = v < 0 ? 0 : v;
     return v >= n ? n - 1 : v;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Split fp16 planes ("SP") of the 256-channel blocks (conv3.hip): [8-channel group][plane][y][x][8 x fp16] at quarter
+// resolution, hi = round(x) (saturating at the largest finite fp16), lo = round(x - hi).
+// ---------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ void split8_sp(const float (&f)[8], u32x4& hi, u32x4& lo) {
+    f16x8 h, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h[i] = (_Float16)__builtin_amdgcn_fmed3f(f[i], -65504.f, 65504.f);
+        l[i] = (_Float16)(f[i] - (float)h[i]);
+    }
+    hi = __builtin_bit_cast(u32x4, h);
+    lo = __builtin_bit_cast(u32x4, l);
+}
+
+// byte offset of (8-channel group, plane, y, x) in an SP tensor of an HxW image (32 bits: one image's planes are at most
+// 4 * 256 * H * W bytes = 1 GiB at the 4096 x 4096 frame's quarter resolution; the image index goes into the 64-bit base)
+__device__ __forceinline__ unsigned sp_offset(int cig, int plane, int y, int x, int H, int W) {
+    return ((((unsigned)cig * 2 + plane) * H + y) * W + x) * 16u;
+}
+#endif
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is per device: set it once per (kernel, device), not once per process
 // (the mask is atomic: entry points may be called from several host threads, one stream each; setting the attribute
@@ -97,9 +122,15 @@ struct vst_prof_scope {
 
 // conv3.hip: one 256-channel stride-1 coupling block on the LDS-DMA kernels.  tmp = [h1 | h2 | planes A | planes B]
 // (vst_block_tmp_bytes).  pos = position 0..10 of the block in a pass's run of eleven such blocks (the state then lives in the
-// split planes between the run's ends), or -1 for a block on its own (fp32 state in, fp32 state out).
+// split planes between the run's ends), or -1 for a block on its own (fp32 state in, fp32 state out).  src_planes_ready: the
+// planes of the run's first src are already in planes A (written by block 20's conv.7 in a forward pass).
 int vst3_block256(const vst_block_weights* w, int direction, int precision, float* dst, const float* src, void* tmp,
-                  int pos, int B, int H, int W, void* stream);
+                  int pos, int src_planes_ready, int B, int H, int W, void* stream);
+// the stride-2 256-channel block's conv.4 (h1 planes -> h2 planes) and conv.7 (h2 planes -> fp32 state read-modify-write,
+// optionally also the new state's planes into planes A) on the same kernels; conv.1 is conv.hip's stride-2 kernel writing planes
+int vst3_conv_mid(const vst_conv_weights* c, const void* in_sp, void* out_sp, int B, int H, int W, void* stream);
+int vst3_conv_out(const vst_conv_weights* c, const void* in_sp, float* state, void* out_sp, float sign, int B, int H, int W,
+                  void* stream);
 
 // internal (not part of the C ABI): input packing with the constant of forward block 0 folded in
 extern "C" int vst_pack_input_k(const float* x, const uint8_t* x_u8, float* s1, float* s2, int B, int C, int H, int W,

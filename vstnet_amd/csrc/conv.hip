@@ -34,6 +34,8 @@ struct ConvArgs {
     int tiles_x, tiles_y, tiles_total;   // 1-D grid of round_up(tiles_total, 8) workgroups, see xcd_tile()
     const unsigned char* packed1;        // conv_pair_kernel: conv.4's packed weights and bias (in = h1)
     const float* bias1;
+    unsigned char* out_sp;               // OUT_SP: the output goes to split fp16 planes (common.h) instead of `out`
+    size_t out_sp_img_bytes;
 };
 
 // Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2.  Give XCD k the contiguous
@@ -160,7 +162,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, float* out_img, in
 #define VST_EARLY_OLD 1
 #endif
 // ---- generic kernel: one tile per workgroup, staging per input-channel chunk (all shapes) --------------
-template <int CIN, int COUT, int STRIDE, bool IN_STATE, bool OUT_STATE>
+template <int CIN, int COUT, int STRIDE, bool IN_STATE, bool OUT_STATE, bool OUT_SP = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     using C = ConvCfg<CIN, COUT, STRIDE>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -321,6 +323,32 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #undef F4
 
     load_bias<COUT, C::NB>(a, co0 + 4 * kg, bias);
+    if constexpr (OUT_SP) {
+        // ReLU(acc + bias) as split fp16 planes for conv3.hip's kernels: the lane's 8 channels {16(2j) + 4kg + r, 16(2j+1) + 4kg + r}
+        static_assert(COUT == 64 && C::NB == 4 && !OUT_STATE, "plane output: the 64-channel intermediates only");
+        unsigned char* const sp_img = a.out_sp + (size_t)b * a.out_sp_img_bytes;
+#pragma unroll
+        for (int m = 0; m < C::MR; ++m) {
+            const int oy = ty0 + wave * C::MR + m, ox = tx0 + lrow;
+            if (oy >= a.Hout || ox >= a.Wout) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float f8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int n = 2 * j + (e >> 2);
+                    const float bb = e & 2 ? (e & 1 ? bias[n].w : bias[n].z) : (e & 1 ? bias[n].y : bias[n].x);
+                    const float v = acc[m][n][e & 3] + bb;
+                    f8[e] = v > 0.f ? v : 0.f;
+                }
+                u32x4 hi, lo;
+                split8_sp(f8, hi, lo);
+                *(u32x4*)(sp_img + sp_offset(j * 4 + kg, 0, oy, ox, a.Hout, a.Wout)) = hi;
+                *(u32x4*)(sp_img + sp_offset(j * 4 + kg, 1, oy, ox, a.Hout, a.Wout)) = lo;
+            }
+        }
+        return;
+    }
     if (OUT_STATE && !EARLY_OLD) fetch_old();
     if (interior) store_tile<COUT, OUT_STATE, C::MR, C::NB, true>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, acc, bias, old);
     else store_tile<COUT, OUT_STATE, C::MR, C::NB>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, acc, bias, old);
@@ -898,6 +926,21 @@ static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) 
     return VST_OK;
 }
 
+// conv.1 of the stride-2 256-channel block with its output written as split planes (the F16X2 path)
+static int launch_conv_s2_planes(const ConvArgs& a, int B, hipStream_t st) {
+    using C = ConvCfg<64, 64, 2>;
+    vst_prof_scope prof(VST_KERNEL_ID(64, 64, 2), st);
+    auto kern = conv_mfma_kernel<64, 64, 2, true, false, true>;
+    static std::atomic<unsigned> attr_done{0};
+    if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)(C::LDS_BYTES), &attr_done)) return rc_;
+    ConvArgs t = a;
+    t.tiles_x = (a.Wout + C::TW - 1) / C::TW; t.tiles_y = (a.Hout + C::TH - 1) / C::TH;
+    t.tiles_total = t.tiles_x * t.tiles_y * B * C::NCOT;
+    kern<<<dim3((t.tiles_total + 7) / 8 * 8), 256, C::LDS_BYTES, st>>>(t);
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
 #ifndef VST_PAIR
 #define VST_PAIR 1
 #endif
@@ -933,6 +976,23 @@ static int run_block(const vst_block_weights* w, int direction, int precision, f
     a.in = src; a.out = h1; a.packed = (const unsigned char*)w->conv[0].packed; a.bias = w->conv[0].bias;
     a.Hin = Ho * STRIDE; a.Win = Wo * STRIDE; a.Hout = Ho; a.Wout = Wo;
     a.in_img_stride = state_img; a.out_img_stride = mid_img; a.sign = 0.f;
+    if constexpr (CH == 256 && STRIDE == 2) {
+        if (precision == VST_PREC_F16X2) {
+            // the F16X2 path: h1 / h2 as split fp16 planes, conv.4 and conv.7 on conv3.hip's kernels.  In a forward pass the
+            // new state half also goes out as planes: it is the src of the run of stride-1 blocks that follows.
+            const size_t mid_bytes = (size_t)Ho * Wo * 64 * 4, state_bytes = (size_t)Ho * Wo * 256 * 4;
+            unsigned char* const h1p = (unsigned char*)tmp;
+            unsigned char* const h2p = h1p + (size_t)B * mid_bytes;
+            unsigned char* const planes_a = h2p + (size_t)B * mid_bytes;
+            (void)state_bytes;
+            a.out_sp = h1p; a.out_sp_img_bytes = mid_bytes;
+            int rc2 = launch_conv_s2_planes(a, B, st);
+            if (rc2) return rc2;
+            rc2 = vst3_conv_mid(&w->conv[1], h1p, h2p, B, H, W, st);
+            if (rc2) return rc2;
+            return vst3_conv_out(&w->conv[2], h2p, dst, direction > 0 ? planes_a : nullptr, direction > 0 ? 1.f : -1.f, B, H, W, st);
+        }
+    }
     int rc = launch_conv<IN_CH, MID, STRIDE, true, false>(a, B, precision, st);
     if (rc) return rc;
     if constexpr (CH <= 64 && VST_PAIR) {
@@ -1039,9 +1099,9 @@ int vst_block_apply(const vst_block_weights* w, int channel, int stride, int dir
     if (channel == 256 && stride == 1) {
         if (precision == VST_PREC_F16X2)
 #if defined(VST_SP_ABLATE) && (VST_SP_ABLATE & 8)
-            return vst3_block256(w, direction, precision, dst, src, tmp, 5, B, H, W, stream);   // diagnostic build: a mid-run block
+            return vst3_block256(w, direction, precision, dst, src, tmp, 5, 0, B, H, W, stream);   // diagnostic build: a mid-run block
 #else
-            return vst3_block256(w, direction, precision, dst, src, tmp, -1, B, H, W, stream);
+            return vst3_block256(w, direction, precision, dst, src, tmp, -1, 0, B, H, W, stream);
 #endif
         return run_block<256, 1>(w, direction, precision, dst, src, t, B, H, W, st);
     }
@@ -1078,7 +1138,7 @@ static int revnet_forward_chunk(const vst_net_weights* w, const float* x, const 
     const bool sp = precision == VST_PREC_F16X2;
     for (int k = fold0 ? 1 : 0; k < VST_NUM_BLOCKS; ++k) {
         if (sp && k >= 21)      // block k's conv.7 leaves the split planes of its dst = block k+1's src
-            rc = vst3_block256(&w->blocks[k], +1, precision, s[k & 1], s[1 - (k & 1)], tmp, k - 21, B, H, W, stream);
+            rc = vst3_block256(&w->blocks[k], +1, precision, s[k & 1], s[1 - (k & 1)], tmp, k - 21, 1, B, H, W, stream);
         else
             rc = vst_block_apply(&w->blocks[k], kBlockChannel[k], kBlockStride[k], +1, precision, s[k & 1], s[1 - (k & 1)],
                                  tmp, B, H, W, stream);
@@ -1098,7 +1158,7 @@ static int revnet_inverse_chunk(const vst_net_weights* w, const float* z, float*
     const bool sp = precision == VST_PREC_F16X2;
     for (int k = VST_NUM_BLOCKS - 1; k >= 0; --k) {
         if (sp && k >= 21)
-            rc = vst3_block256(&w->blocks[k], -1, precision, s[k & 1], s[1 - (k & 1)], tmp, VST_NUM_BLOCKS - 1 - k, B, H, W,
+            rc = vst3_block256(&w->blocks[k], -1, precision, s[k & 1], s[1 - (k & 1)], tmp, VST_NUM_BLOCKS - 1 - k, 0, B, H, W,
                                stream);
         else
             rc = vst_block_apply(&w->blocks[k], kBlockChannel[k], kBlockStride[k], -1, precision, s[k & 1], s[1 - (k & 1)],

@@ -29,9 +29,6 @@
 #define VST_SP_ABLATE 0      // timing-only builds: 1 = no DMA in the main loop, 2 = no MFMAs, 4 = no fragment re-reads
 #endif
 
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-
 struct SpArgs {
     const unsigned char* in;     // SP planes of the input tensor (image 0)
     float* state;                // OUT_STATE: fp32 state half (ZC layout, level 2): the old values unless old_sp is given, and,
@@ -47,27 +44,9 @@ struct SpArgs {
     int tiles_x, tiles_y, tiles_total;
 };
 
-// hi = round(x), lo = round(x - hi); hi saturates at the largest finite fp16 instead of becoming inf
-__device__ __forceinline__ void split8_sp(const float (&f)[8], u32x4& hi, u32x4& lo) {
-    f16x8 h, l;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        h[i] = (_Float16)__builtin_amdgcn_fmed3f(f[i], -65504.f, 65504.f);
-        l[i] = (_Float16)(f[i] - (float)h[i]);
-    }
-    hi = __builtin_bit_cast(u32x4, h);
-    lo = __builtin_bit_cast(u32x4, l);
-}
-
 __device__ __forceinline__ void glds16(const unsigned char* g, unsigned char* lds) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
-}
-
-// byte offset of (8-channel group, plane, y, x) in an SP tensor of an HxW image (32 bits: one image's planes are at most
-// 4 * 256 * H * W bytes = 1 GiB at the 4096 x 4096 frame's quarter resolution; the image index goes into the 64-bit base)
-__device__ __forceinline__ unsigned sp_offset(int cig, int plane, int y, int x, int H, int W) {
-    return ((((unsigned)cig * 2 + plane) * H + y) * W + x) * 16u;
 }
 
 template <int N> __device__ __forceinline__ void sp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -387,8 +366,35 @@ static int launch_sp(SpArgs a, int B, hipStream_t st) {
     return VST_OK;
 }
 
+static const unsigned char* sp_frag(const vst_conv_weights& c, int cout, int cin) {
+    const PackedConvLayout L = packed_conv_layout(cout, cin);
+    return (const unsigned char*)c.packed + L.f32_bytes + 2 * L.frag_bytes;
+}
+
+int vst3_conv_mid(const vst_conv_weights* c, const void* in_sp, void* out_sp, int B, int H, int W, void* stream) {
+    const int Hq = H >> 2, Wq = W >> 2;
+    SpArgs a{};
+    a.H = Hq; a.W = Wq;
+    a.in = (const unsigned char*)in_sp; a.out_sp = (unsigned char*)out_sp;
+    a.in_img_bytes = a.out_img_bytes = (size_t)Hq * Wq * 64 * 4;
+    a.wfrag = sp_frag(*c, 64, 64); a.bias = c->bias;
+    return launch_sp<64, 64, false>(a, B, (hipStream_t)stream);
+}
+
+int vst3_conv_out(const vst_conv_weights* c, const void* in_sp, float* state, void* out_sp, float sign, int B, int H, int W,
+                  void* stream) {
+    const int Hq = H >> 2, Wq = W >> 2;
+    SpArgs a{};
+    a.H = Hq; a.W = Wq; a.state_img_floats = (size_t)Hq * Wq * 256;
+    a.in = (const unsigned char*)in_sp; a.in_img_bytes = (size_t)Hq * Wq * 64 * 4;
+    a.state = state; a.old_sp = nullptr; a.store_f32 = 1;
+    a.out_sp = (unsigned char*)out_sp; a.out_img_bytes = (size_t)Hq * Wq * 256 * 4;
+    a.wfrag = sp_frag(*c, 256, 64); a.bias = c->bias; a.sign = sign;
+    return launch_sp<64, 256, true>(a, B, (hipStream_t)stream);
+}
+
 int vst3_block256(const vst_block_weights* w, int direction, int precision, float* dst, const float* src, void* tmp,
-                  int pos, int B, int H, int W, void* stream) {
+                  int pos, int src_planes_ready, int B, int H, int W, void* stream) {
     if (precision != VST_PREC_F16X2) return VST_E_MODE;
     hipStream_t st = (hipStream_t)stream;
     const int Hq = H >> 2, Wq = W >> 2;
@@ -402,7 +408,7 @@ int vst3_block256(const vst_block_weights* w, int direction, int precision, floa
     const int p = alone ? 0 : pos;
     unsigned char* sp_src = spbuf[p & 1];
     unsigned char* sp_dst = spbuf[(p & 1) ^ 1];
-    if (p == 0) {                  // first block of the run: the planes of its src come from the fp32 state
+    if (p == 0 && !src_planes_ready) {   // first block of the run: the planes of its src come from the fp32 state
         const size_t total = (size_t)B * 32 * Hq * Wq;
         size_t blocks = (total + 255) / 256;
         if (blocks > 16384) blocks = 16384;
