@@ -147,11 +147,13 @@ def test_network_golden(golden, mode, precision):
         assert_close(rec, x, 5e-6, f"{mode}.{tag} inverse(forward(x))")
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("mode,shape", [("photo", (1, 72, 104)), ("photo", (2, 64, 64)), ("art", (1, 40, 136)),
                                         ("photo", (1, 8, 8)), ("art", (3, 8, 12))])
-def test_network_vs_oracle_ragged(mode, shape):
+def test_network_vs_oracle_ragged(mode, shape, precision):
     """tile-edge / tiny / batched shapes against the oracle on the same seeded inputs"""
-    net, sd, sp = make_net(mode)
+    net, sd, sp = make_net(mode, precision)
+    TIGHT = NET_TOL[precision]
     B, H, W = shape
     x = synthetic_frames(B, H, W, seed=11)
     with torch.no_grad():
