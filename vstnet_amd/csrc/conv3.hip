@@ -26,7 +26,8 @@
 #include "common.h"
 
 #ifndef VST_SP_ABLATE
-#define VST_SP_ABLATE 0      // timing-only builds: 1 = no DMA in the main loop, 2 = no MFMAs, 4 = no fragment re-reads
+#define VST_SP_ABLATE 0      // timing-only builds: 1 = no DMA in the main loop, 2 = no MFMAs, 4 = no fragment re-reads,
+                             // 16 = no deferred stores (the whole conv.7 epilogue is then dead code), 32 = no old-state loads
 #endif
 
 struct SpArgs {
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
         // a clamped, valid address and are never stored: no per-load predicate (the compiler would branch around every load and
         // wait for each one).  Plane loads are kept as raw bits (hi in old[m][2j], lo in old[m][2j+1]) and decoded at the slice
         // end: touching them here would be a wait.
-        if (OUT_STATE && slice_end) {
+        if (OUT_STATE && slice_end && !(VST_SP_ABLATE & 32)) {
             const int oxc = ox < W ? ox : W - 1;
 #pragma unroll
             for (int m = 0; m < C::MR; ++m)
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
                     if (9 + k < C::APW) ISSUE_A1(q + 1, 9 + k);
                 }
             }
-            if (pending) {                                   // the previous slice's stores: ONE unit per k-step (the memory pipe
+            if (pending && !(VST_SP_ABLATE & 16)) {                                   // the previous slice's stores: ONE unit per k-step (the memory pipe
                 constexpr int order[12] = {8, 9, 10, 11, 0, 1, 2, 3, 4, 5, 6, 7};   // takes ~24 B/clk per CU: more would stall the
                 if (pend_slot0 == 0) { STORE_UNIT(order[k]); }                      // waves at issue); plane pairs first
                 else if (k < 3) { STORE_UNIT(order[9 + (k < 3 ? k : 0)]); }
