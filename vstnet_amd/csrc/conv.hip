@@ -43,6 +43,34 @@ struct ConvArgs {
 #ifndef VST_XCD_REMAP
 #define VST_XCD_REMAP 1
 #endif
+#ifdef VST_TRACE
+// Diagnostic build only (-DVST_TRACE=1: conv_pair_kernel, 2: conv_mfma_kernel): every workgroup of the LAST traced launch
+// leaves {start, end (100 MHz ticks), HW_ID, XCC_ID} here; tools/trace_grid.py reads them back through vst_trace_dump.
+__device__ unsigned long long vst_trace_buf[4 * 16384];
+#define VST_TRACE_BEGIN(which)                                                                                  \
+    const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();   /* scalar: no VGPR is held for it */
+#define VST_TRACE_END(which)                                                                                    \
+    if (VST_TRACE == (which)) {                                                                                 \
+        __builtin_amdgcn_s_waitcnt(0);                                                                          \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < 16384) {                                                           \
+            unsigned hw, xcc;                                                                                   \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                    \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                                  \
+            vst_trace_buf[4 * blockIdx.x + 0] = trace_t0;                                                       \
+            vst_trace_buf[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();                               \
+            vst_trace_buf[4 * blockIdx.x + 2] = hw;                                                             \
+            vst_trace_buf[4 * blockIdx.x + 3] = xcc;                                                            \
+        }                                                                                                       \
+    }
+extern "C" int vst_trace_dump(unsigned long long* host, int n_wg) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vst_trace_buf), sizeof(unsigned long long) * 4 * (size_t)n_wg);
+}
+#else
+#define VST_TRACE_BEGIN(which)
+#define VST_TRACE_END(which)
+#endif
+
 __device__ __forceinline__ bool xcd_tile(const ConvArgs& a, int& bx, int& by, int& bz) {
     const int g = blockIdx.x, per = gridDim.x >> 3;
     const int n = VST_XCD_REMAP ? (g & 7) * per + (g >> 3) : g;
@@ -175,6 +203,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const int lrow = lane & 15, kg = lane >> 4;
     int bx, by, bz;
     if (!xcd_tile(a, bx, by, bz)) return;
+    VST_TRACE_BEGIN(2)
     const int tx0 = bx * C::TW, ty0 = by * C::TH;
     const int b = bz / C::NCOT, co0 = (bz % C::NCOT) * C::NT;
 
@@ -352,6 +381,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     if (OUT_STATE && !EARLY_OLD) fetch_old();
     if (interior) store_tile<COUT, OUT_STATE, C::MR, C::NB, true>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, acc, bias, old);
     else store_tile<COUT, OUT_STATE, C::MR, C::NB>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, acc, bias, old);
+    VST_TRACE_END(2)
 }
 
 // ---- conv.4 + conv.7 of one stage-1 / stage-2 coupling block in one launch -----------------------------------------
@@ -415,6 +445,7 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const ConvArgs a) {
     const int lrow = lane & 15, kg = lane >> 4;
     int bx, by, b;
     if (!xcd_tile(a, bx, by, b)) return;
+    VST_TRACE_BEGIN(1)
     const int tx0 = bx * C::TW, ty0 = by * C::TH;
     const int H = a.Hout, W = a.Wout;                        // h1, h2 and the output view share one resolution
     const float* const in_img = a.in + (size_t)b * a.in_img_stride;
@@ -624,6 +655,7 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const ConvArgs a) {
 #undef PAIR_FETCH_OLD
     if (interior) store_tile<CH, true, C::MR, C::NB, true>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, 4 * kg, acc, bias, old);
     else store_tile<CH, true, C::MR, C::NB>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, 4 * kg, acc, bias, old);
+    VST_TRACE_END(1)
 }
 
 // ---- pipelined kernel for the MFMA-bound shapes: CIN in {64,256}, COUT in {64,256}, stride 1 --------
