@@ -132,6 +132,11 @@ int vst3_conv_mid(const vst_conv_weights* c, const void* in_sp, void* out_sp, in
 int vst3_conv_out(const vst_conv_weights* c, const void* in_sp, float* state, void* out_sp, float sign, int B, int H, int W,
                   void* stream);
 
+// the split-plane buffer idx (0 = A, 1 = B) inside tmp; layout.hip: gather whose first half goes straight into split planes
+unsigned char* vst3_plane_buffer(void* tmp, int idx, int B, int H, int W);
+extern "C" int vst3_gather_planes(const float* z, unsigned char* s1_planes, float* s2, int B, int H, int W, int sp_steps,
+                                  void* stream);
+
 // internal (not part of the C ABI): input packing with the constant of forward block 0 folded in
 extern "C" int vst_pack_input_k(const float* x, const uint8_t* x_u8, float* s1, float* s2, int B, int C, int H, int W,
                                 const float* addk, void* stream);

@@ -1185,12 +1185,15 @@ static int revnet_inverse_chunk(const vst_net_weights* w, const float* z, float*
     s[0] = (float*)workspace;
     s[1] = s[0] + (size_t)B * H * W * 16;
     float* tmp = s[1] + (size_t)B * H * W * 16;
-    int rc = vst_gather(z, s[0], s[1], B, H, W, sp_steps, stream);
-    if (rc) return rc;
+    // f16x2: the first block (31) reads its src s[0] only as split planes and block 30 takes its old s[0] from them too, so
+    // the gather writes that half straight into plane buffer 0 (no fp32 copy, no pre-split pass)
     const bool sp = precision == VST_PREC_F16X2;
+    int rc = sp ? vst3_gather_planes(z, vst3_plane_buffer(tmp, 0, B, H, W), s[1], B, H, W, sp_steps, stream)
+                : vst_gather(z, s[0], s[1], B, H, W, sp_steps, stream);
+    if (rc) return rc;
     for (int k = VST_NUM_BLOCKS - 1; k >= 0; --k) {
         if (sp && k >= 21)
-            rc = vst3_block256(&w->blocks[k], -1, precision, s[k & 1], s[1 - (k & 1)], tmp, VST_NUM_BLOCKS - 1 - k, 0, B, H, W,
+            rc = vst3_block256(&w->blocks[k], -1, precision, s[k & 1], s[1 - (k & 1)], tmp, VST_NUM_BLOCKS - 1 - k, 1, B, H, W,
                                stream);
         else
             rc = vst_block_apply(&w->blocks[k], kBlockChannel[k], kBlockStride[k], -1, precision, s[k & 1], s[1 - (k & 1)],

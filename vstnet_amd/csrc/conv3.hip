@@ -394,6 +394,12 @@ int vst3_conv_out(const vst_conv_weights* c, const void* in_sp, float* state, vo
     return launch_sp<64, 256, true>(a, B, (hipStream_t)stream);
 }
 
+// the split-plane buffer `idx` (0 / 1) inside a pass's scratch (h1 | h2 | planes 0 | planes 1)
+unsigned char* vst3_plane_buffer(void* tmp, int idx, int B, int H, int W) {
+    const size_t px = (size_t)(H >> 2) * (W >> 2);
+    return (unsigned char*)tmp + (size_t)B * px * 64 * 4 * 2 + (size_t)idx * B * px * 256 * 4;
+}
+
 int vst3_block256(const vst_block_weights* w, int direction, int precision, float* dst, const float* src, void* tmp,
                   int pos, int src_planes_ready, int B, int H, int W, void* stream) {
     if (precision != VST_PREC_F16X2) return VST_E_MODE;
@@ -433,12 +439,13 @@ int vst3_block256(const vst_block_weights* w, int direction, int precision, floa
     a.wfrag = frag(w->conv[1], 64, 64); a.bias = w->conv[1].bias;
     rc = launch_sp<64, 64, false>(a, B, st);
     if (rc) return rc;
-    // conv.7: h2 -> dst += sign * (.).  The old dst values: fp32 for the first two blocks of a run (each half's first update),
-    // afterwards the planes block pos-2 wrote (= this block's dst buffer: read before written, same lane).  The new values go to
+    // conv.7: h2 -> dst += sign * (.).  The old dst values: fp32 for the first block of a run, afterwards the planes of this
+    // block's dst buffer (pos 1: block 0's src planes, from block 20 / the gather; later: what block pos-2 wrote; read before
+    // written, same lane).  The new values go to
     // the planes (the next block's src / the block after's old values) except for the run's last block, and to the fp32 state
     // for the last writer of each half (pos >= 9) and for a block on its own.
     a.in = h2; a.out_img_bytes = state_bytes; a.state = dst;
-    a.old_sp = (!alone && p >= 2) ? sp_dst : nullptr;
+    a.old_sp = (!alone && p >= 1) ? sp_dst : nullptr;
     a.store_f32 = alone || p >= 9;
     a.out_sp = (!alone && p < 10) ? sp_dst : nullptr;
     a.wfrag = frag(w->conv[2], 256, 64); a.bias = w->conv[2].bias;

@@ -127,9 +127,12 @@ struct SpreadGeom {
     }
 };
 
-template <int SP, bool TO_Z>
+// PLANES (gather only): the first half is written as fp16 hi / lo split planes (common.h, SP layout) into `sp1` instead of
+// fp32 into s1 - the inverse pass's first 256-channel block reads its src only through them (conv3.hip).
+template <int SP, bool TO_Z, bool PLANES = false>
 __global__ __launch_bounds__(256) void spread_gather_kernel(float* __restrict__ s1, float* __restrict__ s2,
-                                                            float* __restrict__ z, int H, int W) {
+                                                            float* __restrict__ z, int H, int W,
+                                                            unsigned char* __restrict__ sp1 = nullptr) {
     __shared__ float lds[32 * SpreadGeom<SP>::CELL_STRIDE];
     const int Hq = H >> 2, Wq = W >> 2;
     const int w0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
@@ -138,8 +141,25 @@ __global__ __launch_bounds__(256) void spread_gather_kernel(float* __restrict__ 
     float* half[2] = {s1 + (size_t)b * img, s2 + (size_t)b * img};
 
     auto state_phase = [&]() {
+        if (PLANES) {                                          // half 0: 16 cells x 32 eight-channel groups, both planes
+            unsigned char* const sp_img = sp1 + (size_t)b * img * 4;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
+            for (int it = 0; it < 2; ++it) {
+                const int idx = it * 256 + t;
+                const int cell = idx & 15, cig = idx >> 4;
+                const int w = w0 + cell;
+                if (w >= Wq) continue;
+                const int cot = cig >> 3, j = (cig >> 2) & 1, kg = cig & 3;
+                const int li = SpreadGeom<SP>::lds_index(cell, cot * 64 + j * 32 + kg * 4);
+                const float f8[8] = {lds[li], lds[li + 1], lds[li + 2], lds[li + 3], lds[li + 16], lds[li + 17], lds[li + 18], lds[li + 19]};
+                u32x4 hi, lo;
+                split8_sp(f8, hi, lo);
+                *(u32x4*)(sp_img + sp_offset(cig, 0, h, w, Hq, Wq)) = hi;
+                *(u32x4*)(sp_img + sp_offset(cig, 1, h, w, Hq, Wq)) = lo;
+            }
+        }
+#pragma unroll
+        for (int it = PLANES ? 4 : 0; it < 8; ++it) {
             const int idx = it * 256 + t;
             const int slot = idx >> 6, q = idx & 63;
             const int w = w0 + (slot & 15);
@@ -325,6 +345,20 @@ int vst_spread(const float* s1, const float* s2, float* z, int B, int H, int W, 
     vst_prof_scope prof(VST_KERNEL_SPREAD, st);
     if (sp_steps == 2) spread_gather_kernel<2, true><<<grid, 256, 0, st>>>((float*)s1, (float*)s2, z, H, W);
     else if (sp_steps == 1) spread_gather_kernel<1, true><<<grid, 256, 0, st>>>((float*)s1, (float*)s2, z, H, W);
+    else return VST_E_MODE;
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
+// gather for the f16x2 inverse pass: s1 only as split planes (`s1_planes`, 1024 B per quarter-res pixel and image), s2 in fp32
+int vst3_gather_planes(const float* z, unsigned char* s1_planes, float* s2, int B, int H, int W, int sp_steps, void* stream) {
+    if (!s1_planes || !s2 || !z) return VST_E_ARG;
+    if (!vst_shape_ok(B, H, W)) return VST_E_SHAPE;
+    const dim3 grid((W / 4 + 15) / 16, H / 4, B);
+    hipStream_t st = (hipStream_t)stream;
+    vst_prof_scope prof(VST_KERNEL_GATHER, st);
+    if (sp_steps == 2) spread_gather_kernel<2, false, true><<<grid, 256, 0, st>>>(nullptr, s2, (float*)z, H, W, s1_planes);
+    else if (sp_steps == 1) spread_gather_kernel<1, false, true><<<grid, 256, 0, st>>>(nullptr, s2, (float*)z, H, W, s1_planes);
     else return VST_E_MODE;
     VST_RETURN_IF_LAUNCH_FAILED();
     return VST_OK;
