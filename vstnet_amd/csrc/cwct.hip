@@ -13,7 +13,8 @@
 
 #define CWCT_MAX_STYLES 8
 #ifndef VST_LBL_ABL
-#define VST_LBL_ABL 0        // timing-only builds of cwct_stats_labels_kernel: 1 = no row sums, 2 = no MFMAs, 4 = no staging
+#define VST_LBL_ABL 0        // timing-only builds of cwct_stats_labels_kernel: 1 = no row sums, 2 = no MFMAs, 4 = no staging;
+                             // 128 = cwct_stats_mfma_kernel without its MFMAs
 #endif
 #define CWCT_MAX_TRIES 4096
 
@@ -119,94 +120,98 @@ __global__ __launch_bounds__(256) void cwct_stats_mfma_kernel(const float* __res
     if (p_end > L) p_end = L;
     for (int c = tid; c < N; c += 256) sh[c] = p_begin < L ? x[(size_t)c * L + p_begin] : 0.f;
 
-    // tile prefetch registers: values and per-pixel validity bits of this thread's float4 groups
-    float4 pv[NV];
-    unsigned pm[NV];
-    auto prefetch = [&](long p0) {
-#pragma unroll
-        for (int it = 0; it < NV; ++it) {
-            const int e = it * 256 + tid, c = e >> 4;
-            const long p = p0 + 4 * (e & 15);
-            unsigned m = 0;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (VEC) {
-                if (p < p_end) {                          // p_end, L and p are multiples of 4 here
-                    m = 0xf;
-                    if (mask != nullptr) {
-                        const uchar4 mk = *(const uchar4*)(mask + p);
-                        m = (mk.x == label) | ((mk.y == label) << 1) | ((mk.z == label) << 2) | ((mk.w == label) << 3);
-                    }
-                    if (m) v = *(const float4*)(x + (size_t)c * L + p);     // pixels of other labels are never fetched
-                }
-            } else {
-                float t[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (p + q < p_end) {
-                        t[q] = x[(size_t)c * L + p + q];
-                        m |= (mask == nullptr || mask[p + q] == label) << q;
-                    }
-                v = make_float4(t[0], t[1], t[2], t[3]);
-            }
-            pv[it] = v; pm[it] = m;
-        }
-    };
+    // tile prefetch registers, TWO tiles deep (a workgroup keeps 2 x N x 256 B in flight; with one tile the kernel sat at
+    // 2.4 TB/s): values and per-pixel validity bits of this thread's float4 groups
+    float4 pv[2][NV];
+    unsigned pm[2][NV];
+#define STATS_PREFETCH(S, p0_)                                                                                   \
+    {                                                                                                           \
+        const long p0__ = (p0_);                                                                                \
+        _Pragma("unroll") for (int it = 0; it < NV; ++it) {                                                     \
+            const int e = it * 256 + tid, c = e >> 4;                                                           \
+            const long p = p0__ + 4 * (e & 15);                                                                 \
+            unsigned m = 0;                                                                                     \
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                         \
+            if (VEC) {                                                                                          \
+                if (p < p_end) {                          /* p_end, L and p are multiples of 4 here */          \
+                    m = 0xf;                                                                                    \
+                    if (mask != nullptr) {                                                                      \
+                        const uchar4 mk = *(const uchar4*)(mask + p);                                           \
+                        m = (mk.x == label) | ((mk.y == label) << 1) | ((mk.z == label) << 2) | ((mk.w == label) << 3); \
+                    }                                                                                           \
+                    if (m) v = *(const float4*)(x + (size_t)c * L + p);     /* other labels' pixels: never fetched */ \
+                }                                                                                               \
+            } else {                                                                                            \
+                float t[4] = {0.f, 0.f, 0.f, 0.f};                                                              \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                   \
+                    if (p + q < p_end) {                                                                        \
+                        t[q] = x[(size_t)c * L + p + q];                                                        \
+                        m |= (mask == nullptr || mask[p + q] == label) << q;                                    \
+                    }                                                                                           \
+                v = make_float4(t[0], t[1], t[2], t[3]);                                                        \
+            }                                                                                                   \
+            pv[S][it] = v; pm[S][it] = m;                                                                       \
+        }                                                                                                       \
+    }
 
     f32x16 acc[NBLK];
 #pragma unroll
     for (int b = 0; b < NBLK; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-    float asum = 0.f, cnt = 0.f;                       // row sum of channel tid (tid < N); pixel count (channel-0 owners)
-    prefetch(p_begin);
-    for (long p0 = p_begin; p0 < p_end; p0 += PT) {
-        // barrier: the previous tile's MFMAs are done with xs.  With a mask it also tells whether this 64-pixel tile holds
-        // any pixel of the label at all: the per-label passes of a masked transfer skip everything else (a region's
-        // tiles are mostly single-label, so K label passes cost about one pass)
-        if (mask != nullptr) {
-            unsigned anym = 0;
-#pragma unroll
-            for (int it = 0; it < NV; ++it) anym |= pm[it];
-            if (!__syncthreads_or((int)anym)) {
-                if (p0 + PT < p_end) prefetch(p0 + PT);
-                continue;
-            }
-        } else {
-            __syncthreads();
-        }
-#pragma unroll
-        for (int it = 0; it < NV; ++it) {
-            const int e = it * 256 + tid, c = e >> 4, pl = 4 * (e & 15);
-            const float s0 = sh[c];
-            const unsigned m = pm[it];
-            float* d = xs + c * LD + pl;
-            d[0] = (m & 1) ? pv[it].x - s0 : 0.f;
-            d[1] = (m & 2) ? pv[it].y - s0 : 0.f;
-            d[2] = (m & 4) ? pv[it].z - s0 : 0.f;
-            d[3] = (m & 8) ? pv[it].w - s0 : 0.f;
-            if (c == 0) cnt += (float)__popc(m);
-        }
-        __syncthreads();
-        if (p0 + PT < p_end) prefetch(p0 + PT);        // in flight during the row sums and MFMAs below
-        if (tid < N) {
-            float sacc = 0.f;
-#pragma unroll 8
-            for (int pl = 0; pl < PT; ++pl) sacc += xs[tid * LD + pl];
-            asum += sacc;
-        }
-        const float* base = xs + (lane & 31) * LD + pg * PPG + (lane >> 5);
-#pragma unroll 4
-        for (int t = 0; t < PPG / 2; ++t) {
-            float f[NBLK];
-#pragma unroll
-            for (int b = 0; b < NBLK; ++b) f[b] = base[b * 32 * LD + 2 * t];
-            float fa = f[0];                              // f[rb] without a runtime register index
-#pragma unroll
-            for (int b = 1; b < NBLK; ++b) fa = rb == b ? f[b] : fa;
-#pragma unroll
-            for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, f[b], acc[b], 0, 0, 0);
-        }
+    float asum[NV], cnt = 0.f;                         // shifted row sums of this thread's (channel, 4-pixel column) groups;
+#pragma unroll                                         // pixel count (channel-0 owners)
+    for (int it = 0; it < NV; ++it) asum[it] = 0.f;
+    // one 64-pixel tile from prefetch slot S; refills the slot with the tile two ahead once its values are in LDS
+#define STATS_TILE(S, p0_)                                                                                       \
+    {                                                                                                           \
+        const long p0t = (p0_);                                                                                 \
+        /* barrier: the previous tile's MFMAs are done with xs.  With a mask it also tells whether this 64-pixel tile */ \
+        /* holds any pixel of the label at all: the per-label passes of a masked transfer skip everything else */  \
+        bool live = true;                                                                                       \
+        if (mask != nullptr) {                                                                                  \
+            unsigned anym = 0;                                                                                  \
+            _Pragma("unroll") for (int it = 0; it < NV; ++it) anym |= pm[S][it];                                \
+            live = __syncthreads_or((int)anym);                                                                 \
+        } else {                                                                                                \
+            __syncthreads();                                                                                    \
+        }                                                                                                       \
+        if (live) {                                                                                             \
+            _Pragma("unroll") for (int it = 0; it < NV; ++it) {                                                 \
+                const int e = it * 256 + tid, c = e >> 4, pl = 4 * (e & 15);                                    \
+                const float s0 = sh[c];                                                                         \
+                const unsigned m = pm[S][it];                                                                   \
+                float* d = xs + c * LD + pl;                                                                    \
+                const float d0 = (m & 1) ? pv[S][it].x - s0 : 0.f, d1 = (m & 2) ? pv[S][it].y - s0 : 0.f;       \
+                const float d2 = (m & 4) ? pv[S][it].z - s0 : 0.f, d3 = (m & 8) ? pv[S][it].w - s0 : 0.f;       \
+                d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3;                                                     \
+                asum[it] += (d0 + d1) + (d2 + d3);       /* row sums: per staging thread, reduced once at the end */ \
+                if (c == 0) cnt += (float)__popc(m);                                                            \
+            }                                                                                                   \
+            __syncthreads();                                                                                    \
+        }                                                                                                       \
+        if (p0t + 2 * PT < p_end) STATS_PREFETCH(S, p0t + 2 * PT)   /* in flight during two tiles' row sums and MFMAs */ \
+        if (live) {                                                                                             \
+            const float* base = xs + (lane & 31) * LD + pg * PPG + (lane >> 5);                                 \
+            _Pragma("unroll 4") for (int t = 0; t < PPG / 2; ++t) {                                             \
+                float f[NBLK];                                                                                  \
+                _Pragma("unroll") for (int b = 0; b < NBLK; ++b) f[b] = base[b * 32 * LD + 2 * t];              \
+                float fa = f[0];                              /* f[rb] without a runtime register index */      \
+                _Pragma("unroll") for (int b = 1; b < NBLK; ++b) fa = rb == b ? f[b] : fa;                      \
+                if (!(VST_LBL_ABL & 128))                                                                       \
+                _Pragma("unroll") for (int b = 0; b < NBLK; ++b)                                                \
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, f[b], acc[b], 0, 0, 0);                   \
+            }                                                                                                   \
+        }                                                                                                       \
     }
+    STATS_PREFETCH(0, p_begin)
+    if (p_begin + PT < p_end) STATS_PREFETCH(1, p_begin + PT)
+    for (long p0 = p_begin; p0 < p_end; p0 += 2 * PT) {
+        STATS_TILE(0, p0)
+        if (p0 + PT < p_end) STATS_TILE(1, p0 + PT)
+    }
+#undef STATS_TILE
+#undef STATS_PREFETCH
     // ---- combine the pixel groups (PG > 1) through LDS, then one record per workgroup ------------------------------
     float* rec = partial + (size_t)blockIdx.x * cwct_partial_stride(N);
     if (PG > 1) {
@@ -239,7 +244,14 @@ __global__ __launch_bounds__(256) void cwct_stats_mfma_kernel(const float* __res
         rec[0] = c2;
     }
     for (int c = tid; c < N; c += 256) rec[4 + c] = sh[c];
-    if (tid < N) rec[4 + N + tid] = asum;
+    // row sums: the 16 lanes e & 15 = 0..15 of a staging group hold the columns of one channel c = e >> 4
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+        float v = asum[it];
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) v += __shfl_xor(v, o, 16);
+        if ((tid & 15) == 0) rec[4 + N + ((it * 256 + tid) >> 4)] = v;
+    }
     if (pg == 0) {
 #pragma unroll
         for (int b = 0; b < NBLK; ++b)
