@@ -855,6 +855,7 @@ def test_single_pass_masked_transfer_hard_cases():
 def test_transfer_with_stats_inplace():
     from models.cWCT import cWCT
     net, sd, sp = make_net("photo")
+    net.packed_code = False                     # the dense [B,32,H,W] form of the code (packed codes are never written by cWCT)
     cw = cWCT()
     with torch.no_grad():
         stats = cw.style_stats(net(synthetic_frames(1, 40, 56, seed=9).cuda()))
@@ -863,3 +864,51 @@ def test_transfer_with_stats_inplace():
         keep = zc.clone()
         out = cw.transfer_with_stats(zc, stats, inplace=True)
         assert out.data_ptr() == zc.data_ptr() and torch.equal(out, ref) and not torch.equal(zc, keep)
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "bf16x3", "fp32"])
+def test_packed_code_equals_dense_path(precision):
+    """net(x) in photorealistic mode returns a PackedCode (vstnet_amd/code.py): the code in the coupling blocks' own layout.
+    It must be the same [B,32,H,W] tensor to every caller, and encode -> cWCT -> decode on the packed rows must give what the
+    dense path (spread, NCHW cWCT, gather; checked against the oracle elsewhere in this file) gives.  Shapes include
+    H*W not a multiple of 32 (row tiles straddle the halves / the end) and a batch."""
+    from models.cWCT import cWCT
+    from vstnet_amd.code import PackedCode, from_dense
+    net, sd, sp = make_net("photo", precision)
+    dense, _, _ = make_net("photo", precision)
+    dense.packed_code = False
+    cw = cWCT(precision=precision)
+    for B, H, W in ((1, 12, 20), (2, 40, 24), (1, 64, 96), (1, 256, 320)):
+        x, xs = synthetic_frames(B, H, W, seed=5).cuda(), synthetic_frames(B, H + 8, W - 4, seed=6).cuda()
+        with torch.no_grad():
+            z, zd = net(x), dense(x)
+            assert isinstance(z, PackedCode) and not isinstance(zd, PackedCode)
+            assert z.shape == zd.shape and z.dtype == zd.dtype and z.device == zd.device
+            assert torch.equal(z.materialize(), zd), "the packed rows are a permutation of z"
+            assert torch.equal(z * 2.0, zd * 2.0) and torch.equal(z[:, 3:5].contiguous(), zd[:, 3:5].contiguous())
+            assert torch.equal(from_dense(zd).materialize(), zd)
+            assert torch.equal(net(z, forward=False), dense(zd, forward=False)), "plain decode"
+            assert torch.equal(net(from_dense(zd), forward=False), dense(zd, forward=False))
+            zs, zsd = net(xs), dense(xs)
+            t, td = cw.transfer(z, zs), cw.transfer(zd, zsd)
+            assert isinstance(t, PackedCode) and t.pending_affines is not None
+            assert_close(t.materialize(), td, 2e-5, f"transfer on packed rows {B}x{H}x{W}")
+            out, outd = net(t, forward=False), dense(td, forward=False)
+            assert float((out - outd).abs().max()) <= 2e-5
+            # cached style statistics, a mix of two styles with a content share, and the uint8 edge
+            assert float((net(cw.transfer_with_stats(z, cw.style_stats(zs)), forward=False) - outd).abs().max()) <= 2e-5
+            mix, mixd = cw.interpolation(z, [zs, z], [0.6, 0.4], 0.3), cw.interpolation(zd, [zsd, zd], [0.6, 0.4], 0.3)
+            assert_close(mix.materialize(), mixd, 2e-5, "interpolation on packed rows")
+            u8, u8d = net.inverse_u8(t), dense.inverse_u8(td)
+            assert int((u8.int() - u8d.int()).abs().max()) <= 1            # truncation of values 1e-6 apart
+            # a second cWCT on a result, and a masked one, fall back to the dense code
+            again = cw.transfer(t, zs)
+            assert not isinstance(again, PackedCode)
+            assert_close(again, cw.transfer(td, zsd), 2e-5, "cWCT of a cWCT result")
+    # parity with the oracle through the packed path
+    x, xs = synthetic_frames(1, 48, 64, seed=0), synthetic_frames(1, 48, 64, seed=1)
+    with torch.no_grad():
+        got = net(cw.transfer(net(x.cuda()), net(xs.cuda())), forward=False)
+    zc, zs_ = cpu_ref.revnet_forward(x, sd, sp), cpu_ref.revnet_forward(xs, sd, sp)
+    ref = cpu_ref.revnet_inverse(cpu_ref.transfer(zc, zs_), sd, sp)
+    assert_close(got, ref, 2e-4 if precision == "f16x2" else TIGHT, "stylised frame through the packed code vs oracle")

@@ -91,6 +91,22 @@ def test_no_cpu_fallback():
         cw.interpolation(torch.zeros(1, 32, 8, 8), [torch.zeros(1, 32, 8, 8)], [0.5, 0.5])
 
 
+def test_packed_code_host_side():
+    """PackedCode (vstnet_amd/code.py) without a GPU: it presents [B,32,H,W] float32 metadata, carries its pending affine
+    maps, and any torch operation on it goes to the HIP library (no torch / CPU fallback): here that must fail loudly."""
+    from vstnet_amd.code import PackedCode
+    rows = torch.zeros(2, 32 * 16 * 24)
+    z = PackedCode(rows, 16, 24)
+    assert tuple(z.shape) == (2, 32, 16, 24) and z.dtype == torch.float32 and z.device == rows.device
+    assert z.pending_affines is None and z.packed is rows and "PackedCode" in repr(z)
+    t = z.with_affines(torch.zeros(2, 32 * 32 + 32))
+    assert t.packed is rows and t.pending_affines.shape == (2, 1056) and tuple(t.shape) == tuple(z.shape)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        z + 1.0
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        t.materialize()
+
+
 def test_product_does_not_import_oracle():
     for root, _, files in os.walk(os.path.join(REPO, "vstnet_amd")):
         for f in files:

@@ -98,16 +98,28 @@ int main(int argc, char** argv) {
     HIP_OK(hipMemcpyAsync(d_s, style.data(), style.size(), hipMemcpyHostToDevice, st));
 
     // ---- the hot path ---------------------------------------------------------------------------------------------------
-    VST_CALL(vst_revnet_forward_u8(&net, d_c, z_c, ws, 1, H, W, sp, prec, st));
-    VST_CALL(vst_revnet_forward_u8(&net, d_s, z_s, ws, 1, Hs, Ws, sp, prec, st));
-    VST_CALL(vst_cwct_stats(z_s, N, Ls, nullptr, 0, st_s, cws, st));
-    VST_CALL(vst_cwct_prefactor(st_s, N, 2e-5f, st_s, info, st));
-    VST_CALL(vst_cwct_stats(z_c, N, L, nullptr, 0, st_c, cws, st));
     const double* styles[1] = {st_s};
     const float alphas[1] = {1.f};
-    VST_CALL(vst_cwct_factor(st_c, styles, alphas, 1, 0.f, 2e-5f, N, affine, info, st));
-    VST_CALL(vst_cwct_apply_prec(z_c, z_cs, N, L, affine, nullptr, 0, prec, st));
-    VST_CALL(vst_revnet_inverse_u8(&net, z_cs, d_out, ws, 1, H, W, sp, prec, st));
+    if (sp == 2) {
+        // photorealistic: the code stays in the coupling blocks' layout ("Packed code" in vstnet.h): no spread / gather, the
+        // statistics run on the packed rows and the affine map is applied while the inverse pass loads its state
+        VST_CALL(vst_revnet_encode_u8(&net, d_c, z_c, ws, 1, H, W, prec, st));
+        VST_CALL(vst_revnet_encode_u8(&net, d_s, z_s, ws, 1, Hs, Ws, prec, st));
+        VST_CALL(vst_cwct_stats_code(z_s, Hs, Ws, st_s, cws, st));
+        VST_CALL(vst_cwct_prefactor(st_s, N, 2e-5f, st_s, info, st));
+        VST_CALL(vst_cwct_stats_code(z_c, H, W, st_c, cws, st));
+        VST_CALL(vst_cwct_factor(st_c, styles, alphas, 1, 0.f, 2e-5f, N, affine, info, st));
+        VST_CALL(vst_revnet_decode_u8(&net, z_c, affine, d_out, ws, 1, H, W, prec, st));
+    } else {
+        VST_CALL(vst_revnet_forward_u8(&net, d_c, z_c, ws, 1, H, W, sp, prec, st));
+        VST_CALL(vst_revnet_forward_u8(&net, d_s, z_s, ws, 1, Hs, Ws, sp, prec, st));
+        VST_CALL(vst_cwct_stats(z_s, N, Ls, nullptr, 0, st_s, cws, st));
+        VST_CALL(vst_cwct_prefactor(st_s, N, 2e-5f, st_s, info, st));
+        VST_CALL(vst_cwct_stats(z_c, N, L, nullptr, 0, st_c, cws, st));
+        VST_CALL(vst_cwct_factor(st_c, styles, alphas, 1, 0.f, 2e-5f, N, affine, info, st));
+        VST_CALL(vst_cwct_apply_prec(z_c, z_cs, N, L, affine, nullptr, 0, prec, st));
+        VST_CALL(vst_revnet_inverse_u8(&net, z_cs, d_out, ws, 1, H, W, sp, prec, st));
+    }
 
     std::vector<uint8_t> out(content.size());
     HIP_OK(hipMemcpyAsync(out.data(), d_out, out.size(), hipMemcpyDeviceToHost, st));

@@ -1,0 +1,105 @@
+"""PackedCode: the photorealistic code z = RevResNet(x) kept in the layout the coupling blocks leave it in.
+
+The reference's forward pass ends with merge + two unsqueeze steps (models/RevResNet.py:139-144, :219-222) and its inverse
+begins by undoing them (:148-154, :228-231): pure (channel, pixel) permutations, 2 x 256 MB of HBM traffic per 1024x1024
+frame.  An unmasked cWCT (models/cWCT.py:24-47, :206-262) does not depend on the order of the pixels, so on the video path
+encode -> cWCT -> decode nobody needs z in NCHW order.  ``net(x)`` therefore returns a PackedCode: a tensor that *is*
+``[B, 32, H, W]`` float32 to every caller (shape, dtype, device; any torch operation on it first materialises the NCHW
+values, once, with the library's spread kernel), while ``cWCT.transfer / interpolation / transfer_with_stats`` and
+``net(z, forward=False)`` recognise it and work on the packed rows directly (include/vstnet.h, "Packed code").
+A cWCT result is a PackedCode with a pending affine map per image, applied while the inverse pass loads its state.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch.utils._pytree import tree_map
+
+from . import _lib
+
+
+def _stream_ptr() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class PackedCode(torch.Tensor):
+    """float[B][2][H/4][W/4][256] behind the interface of a [B,32,H,W] tensor (see the module docstring)."""
+
+    @staticmethod
+    def __new__(cls, code, H, W, affines=None):
+        B = code.shape[0]
+        r = torch.Tensor._make_wrapper_subclass(cls, (B, 32, H, W), dtype=torch.float32, device=code.device,
+                                                requires_grad=False)
+        r._code = code            # flat float32 [B, 32*H*W], packed rows
+        r._hw = (H, W)
+        r._affines = affines      # None, or float32 [B, 32*32+32]: y = T x + t0 still to be applied to every row of image b
+        r._dense = None
+        return r
+
+    def __repr__(self):
+        H, W = self._hw
+        return f"PackedCode(B={self._code.shape[0]}, H={H}, W={W}, pending_affine={self._affines is not None})"
+
+    @property
+    def packed(self):
+        return self._code
+
+    @property
+    def pending_affines(self):
+        return self._affines
+
+    def _need_gpu(self):
+        if not self._code.is_cuda:
+            raise RuntimeError("vstnet_amd.PackedCode lives on ROCm devices only (no CPU fallback)")
+
+    def with_affines(self, affines):
+        """The same packed rows with the affine map of a cWCT attached (composition is not supported: materialise first)."""
+        assert self._affines is None
+        H, W = self._hw
+        return PackedCode(self._code, H, W, affines)
+
+    def applied(self):
+        """Packed rows with the pending affine map applied (a new buffer), or the rows themselves if none is pending."""
+        if self._affines is None:
+            return self._code
+        self._need_gpu()
+        L = _lib.lib()
+        H, W = self._hw
+        out = torch.empty_like(self._code)
+        with torch.cuda.device(self._code.device):
+            for b in range(self._code.shape[0]):
+                _lib.check(L.vst_cwct_apply_code(C.c_void_p(self._code[b].data_ptr()), C.c_void_p(out[b].data_ptr()), H, W,
+                                                 C.c_void_p(self._affines[b].data_ptr()), _stream_ptr()), "vst_cwct_apply_code")
+        return out
+
+    def materialize(self):
+        """The [B,32,H,W] values (NCHW, a plain tensor), computed once."""
+        if self._dense is None:
+            self._need_gpu()
+            L = _lib.lib()
+            H, W = self._hw
+            rows = self.applied()
+            z = torch.empty((rows.shape[0], 32, H, W), dtype=torch.float32, device=rows.device)
+            with torch.cuda.device(rows.device):
+                _lib.check(L.vst_code_to_z(C.c_void_p(rows.data_ptr()), C.c_void_p(z.data_ptr()), rows.shape[0], H, W,
+                                           _stream_ptr()), "vst_code_to_z")
+            self._dense = z
+        return self._dense
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        def unwrap(t):
+            return t.materialize() if isinstance(t, PackedCode) else t
+        return func(*tree_map(unwrap, args), **tree_map(unwrap, kwargs or {}))
+
+
+def from_dense(z):
+    """Pack a plain [B,32,H,W] code (vst_z_to_code)."""
+    L = _lib.lib()
+    z = z.detach().to(torch.float32).contiguous()
+    B, _, H, W = z.shape
+    code = torch.empty((B, 32 * H * W), dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        _lib.check(L.vst_z_to_code(C.c_void_p(z.data_ptr()), C.c_void_p(code.data_ptr()), B, H, W, _stream_ptr()), "vst_z_to_code")
+    return PackedCode(code, H, W)

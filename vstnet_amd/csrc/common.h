@@ -137,6 +137,11 @@ unsigned char* vst3_plane_buffer(void* tmp, int idx, int B, int H, int W);
 extern "C" int vst3_gather_planes(const float* z, unsigned char* s1_planes, float* s2, int B, int H, int W, int sp_steps,
                                   void* stream);
 
+int vst3_presplit(const float* state, unsigned char* planes, int B, int H, int W, void* stream);
+// cwct.hip: y = T x + t0 on the rows of one image's packed code; half 0 to out0 or (planes0 != nullptr) to split planes
+int vst3_apply_code(const float* code, float* out0, float* out1, unsigned char* planes0, int H, int W, const float* affine,
+                    void* stream);
+
 // internal (not part of the C ABI): input packing with the constant of forward block 0 folded in
 extern "C" int vst_pack_input_k(const float* x, const uint8_t* x_u8, float* s1, float* s2, int B, int C, int H, int W,
                                 const float* addk, void* stream);

@@ -1153,12 +1153,9 @@ static int pass_sub_batch(int B, int H, int W) {
     return nb > (size_t)B ? B : (int)nb;
 }
 
-static int revnet_forward_chunk(const vst_net_weights* w, const float* x, const uint8_t* x_u8, float* z, void* workspace,
-                                int B, int C_in, int H, int W, int sp_steps, int precision, void* stream) {
-    float* s[2];
-    s[0] = (float*)workspace;
-    s[1] = s[0] + (size_t)B * H * W * 16;
-    float* tmp = s[1] + (size_t)B * H * W * 16;
+// the 32 coupling blocks of a forward pass on the state halves s[0], s[1] (n images each), input packing included
+static int forward_blocks(const vst_net_weights* w, const float* x, const uint8_t* x_u8, float* const s[2], float* tmp, int B,
+                          int C_in, int H, int W, int precision, void* stream) {
     // forward block 0 has x2 = 0: F(0) is a per-channel constant that the pack kernel adds (fp32 diagnostic mode keeps
     // the literal three convolutions)
     const bool fold0 = precision != VST_PREC_FP32;
@@ -1176,21 +1173,26 @@ static int revnet_forward_chunk(const vst_net_weights* w, const float* x, const 
                                  tmp, B, H, W, stream);
         if (rc) return rc;
     }
-    return vst_spread(s[0], s[1], z, B, H, W, sp_steps, stream);
+    return VST_OK;
 }
 
-static int revnet_inverse_chunk(const vst_net_weights* w, const float* z, float* x, uint8_t* x_u8, void* workspace, int B,
-                                int C_out, int H, int W, int sp_steps, int precision, void* stream) {
+static int revnet_forward_chunk(const vst_net_weights* w, const float* x, const uint8_t* x_u8, float* z, void* workspace,
+                                int B, int C_in, int H, int W, int sp_steps, int precision, void* stream) {
     float* s[2];
     s[0] = (float*)workspace;
     s[1] = s[0] + (size_t)B * H * W * 16;
     float* tmp = s[1] + (size_t)B * H * W * 16;
-    // f16x2: the first block (31) reads its src s[0] only as split planes and block 30 takes its old s[0] from them too, so
-    // the gather writes that half straight into plane buffer 0 (no fp32 copy, no pre-split pass)
-    const bool sp = precision == VST_PREC_F16X2;
-    int rc = sp ? vst3_gather_planes(z, vst3_plane_buffer(tmp, 0, B, H, W), s[1], B, H, W, sp_steps, stream)
-                : vst_gather(z, s[0], s[1], B, H, W, sp_steps, stream);
+    const int rc = forward_blocks(w, x, x_u8, s, tmp, B, C_in, H, W, precision, stream);
     if (rc) return rc;
+    return vst_spread(s[0], s[1], z, B, H, W, sp_steps, stream);
+}
+
+// the 32 coupling blocks of an inverse pass on the state halves (f16x2: s[0] is given as split planes in plane buffer 0 of
+// tmp - block 31 reads its src only through them and block 30 takes its old values from them too), output unpacking included
+static int inverse_blocks(const vst_net_weights* w, float* x, uint8_t* x_u8, float* const s[2], float* tmp, int B, int C_out,
+                          int H, int W, int precision, void* stream) {
+    const bool sp = precision == VST_PREC_F16X2;
+    int rc = VST_OK;
     for (int k = VST_NUM_BLOCKS - 1; k >= 0; --k) {
         if (sp && k >= 21)
             rc = vst3_block256(&w->blocks[k], -1, precision, s[k & 1], s[1 - (k & 1)], tmp, VST_NUM_BLOCKS - 1 - k, 1, B, H, W,
@@ -1201,6 +1203,68 @@ static int revnet_inverse_chunk(const vst_net_weights* w, const float* z, float*
         if (rc) return rc;
     }
     return x_u8 ? vst_unpack_output_u8(s[0], x_u8, B, H, W, stream) : vst_unpack_output(s[0], x, B, C_out, H, W, stream);
+}
+
+static int revnet_inverse_chunk(const vst_net_weights* w, const float* z, float* x, uint8_t* x_u8, void* workspace, int B,
+                                int C_out, int H, int W, int sp_steps, int precision, void* stream) {
+    float* s[2];
+    s[0] = (float*)workspace;
+    s[1] = s[0] + (size_t)B * H * W * 16;
+    float* tmp = s[1] + (size_t)B * H * W * 16;
+    // f16x2: the gather writes s[0] straight into plane buffer 0 (no fp32 copy, no pre-split pass)
+    const bool sp = precision == VST_PREC_F16X2;
+    const int rc = sp ? vst3_gather_planes(z, vst3_plane_buffer(tmp, 0, B, H, W), s[1], B, H, W, sp_steps, stream)
+                      : vst_gather(z, s[0], s[1], B, H, W, sp_steps, stream);
+    if (rc) return rc;
+    return inverse_blocks(w, x, x_u8, s, tmp, B, C_out, H, W, precision, stream);
+}
+
+// Packed code (photorealistic mode): the state halves themselves, per image [2][H/4][W/4][256] floats = one 32-float row per
+// full-resolution pixel.  encode = forward pass without the spread, one image at a time (its halves are the pass's state
+// buffers); decode = [affine map of an unmasked cWCT on the rows ->] inverse pass without the gather.
+static int revnet_encode_any(const vst_net_weights* w, const float* x, const uint8_t* x_u8, float* code, void* workspace, int B,
+                             int C_in, int H, int W, int precision, void* stream) {
+    if (!w || (!x && !x_u8) || !code) return VST_E_ARG;
+    if (!workspace) return VST_E_WORKSPACE;
+    if (!vst_shape_ok(B, H, W) || C_in < 1 || C_in > 16) return VST_E_SHAPE;
+    const size_t img = (size_t)32 * H * W;
+    float* tmp = (float*)workspace + img;                    // the scratch part of a one-image pass workspace
+    for (int b = 0; b < B; ++b) {
+        float* s[2] = {code + b * img, code + b * img + img / 2};
+        const int rc = forward_blocks(w, x ? x + (size_t)b * C_in * H * W : nullptr, x_u8 ? x_u8 + (size_t)b * H * W * 3 : nullptr,
+                                      s, tmp, 1, C_in, H, W, precision, stream);
+        if (rc) return rc;
+    }
+    return VST_OK;
+}
+
+static int revnet_decode_any(const vst_net_weights* w, const float* code, const float* affines, float* x, uint8_t* x_u8,
+                             void* workspace, int B, int C_out, int H, int W, int precision, void* stream) {
+    if (!w || (!x && !x_u8) || !code) return VST_E_ARG;
+    if (!workspace) return VST_E_WORKSPACE;
+    if (!vst_shape_ok(B, H, W) || C_out < 1 || C_out > 16) return VST_E_SHAPE;
+    const size_t img = (size_t)32 * H * W;
+    float* s[2] = {(float*)workspace, (float*)workspace + img / 2};
+    float* tmp = (float*)workspace + img;
+    const bool sp = precision == VST_PREC_F16X2;
+    unsigned char* planes0 = sp ? vst3_plane_buffer(tmp, 0, 1, H, W) : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    for (int b = 0; b < B; ++b) {
+        const float* c = code + b * img;
+        int rc;
+        if (affines) {
+            rc = vst3_apply_code(c, s[0], s[1], planes0, H, W, affines + (size_t)b * (32 * 32 + 32), stream);
+        } else {                                             // plain copy into the pass's state (it is updated in place)
+            rc = sp ? vst3_presplit(c, planes0, 1, H, W, stream)
+                    : (int)hipMemcpyAsync(s[0], c, img / 2 * sizeof(float), hipMemcpyDeviceToDevice, st);
+            if (!rc) rc = (int)hipMemcpyAsync(s[1], c + img / 2, img / 2 * sizeof(float), hipMemcpyDeviceToDevice, st);
+        }
+        if (rc) return rc;
+        rc = inverse_blocks(w, x ? x + (size_t)b * C_out * H * W : nullptr, x_u8 ? x_u8 + (size_t)b * H * W * 3 : nullptr, s, tmp,
+                            1, C_out, H, W, precision, stream);
+        if (rc) return rc;
+    }
+    return VST_OK;
 }
 
 static int revnet_forward_any(const vst_net_weights* w, const float* x, const uint8_t* x_u8, float* z, void* workspace,
@@ -1261,6 +1325,50 @@ int vst_revnet_inverse_u8(const vst_net_weights* w, const float* z, uint8_t* fra
                           int W, int sp_steps, int precision, void* stream) {
     if (!frames_hwc) return VST_E_ARG;
     return revnet_inverse_any(w, z, nullptr, frames_hwc, workspace, B, 3, H, W, sp_steps, precision, stream);
+}
+
+int vst_revnet_encode(const vst_net_weights* w, const float* x, float* code, void* workspace, int B, int C_in, int H, int W,
+                      int precision, void* stream) {
+    if (!x) return VST_E_ARG;
+    return revnet_encode_any(w, x, nullptr, code, workspace, B, C_in, H, W, precision, stream);
+}
+
+int vst_revnet_encode_u8(const vst_net_weights* w, const uint8_t* frames_hwc, float* code, void* workspace, int B, int H, int W,
+                         int precision, void* stream) {
+    if (!frames_hwc) return VST_E_ARG;
+    return revnet_encode_any(w, nullptr, frames_hwc, code, workspace, B, 3, H, W, precision, stream);
+}
+
+int vst_revnet_decode(const vst_net_weights* w, const float* code, const float* affines, float* x, void* workspace, int B,
+                      int C_out, int H, int W, int precision, void* stream) {
+    if (!x) return VST_E_ARG;
+    return revnet_decode_any(w, code, affines, x, nullptr, workspace, B, C_out, H, W, precision, stream);
+}
+
+int vst_revnet_decode_u8(const vst_net_weights* w, const float* code, const float* affines, uint8_t* frames_hwc, void* workspace,
+                         int B, int H, int W, int precision, void* stream) {
+    if (!frames_hwc) return VST_E_ARG;
+    return revnet_decode_any(w, code, affines, nullptr, frames_hwc, workspace, B, 3, H, W, precision, stream);
+}
+
+int vst_code_to_z(const float* code, float* z, int B, int H, int W, void* stream) {
+    if (!code || !z) return VST_E_ARG;
+    const size_t img = (size_t)32 * H * W;
+    for (int b = 0; b < B; ++b) {
+        const int rc = vst_spread(code + b * img, code + b * img + img / 2, z + b * img, 1, H, W, 2, stream);
+        if (rc) return rc;
+    }
+    return VST_OK;
+}
+
+int vst_z_to_code(const float* z, float* code, int B, int H, int W, void* stream) {
+    if (!code || !z) return VST_E_ARG;
+    const size_t img = (size_t)32 * H * W;
+    for (int b = 0; b < B; ++b) {
+        const int rc = vst_gather(z + b * img, code + b * img, code + b * img + img / 2, 1, H, W, 2, stream);
+        if (rc) return rc;
+    }
+    return VST_OK;
 }
 
 }  // extern "C"

@@ -394,6 +394,19 @@ int vst3_conv_out(const vst_conv_weights* c, const void* in_sp, float* state, vo
     return launch_sp<64, 256, true>(a, B, (hipStream_t)stream);
 }
 
+// fp32 half state [B][H/4][W/4][256] -> its split planes
+int vst3_presplit(const float* state, unsigned char* planes, int B, int H, int W, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int Hq = H >> 2, Wq = W >> 2;
+    const size_t total = (size_t)B * 32 * Hq * Wq;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    vst_prof_scope prof(VST_KERNEL_PRESPLIT, st);
+    presplit_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(state, planes, B, Hq, Wq);
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
 // the split-plane buffer `idx` (0 / 1) inside a pass's scratch (h1 | h2 | planes 0 | planes 1)
 unsigned char* vst3_plane_buffer(void* tmp, int idx, int B, int H, int W) {
     const size_t px = (size_t)(H >> 2) * (W >> 2);
@@ -416,12 +429,7 @@ int vst3_block256(const vst_block_weights* w, int direction, int precision, floa
     unsigned char* sp_src = spbuf[p & 1];
     unsigned char* sp_dst = spbuf[(p & 1) ^ 1];
     if (p == 0 && !src_planes_ready) {   // first block of the run: the planes of its src come from the fp32 state
-        const size_t total = (size_t)B * 32 * Hq * Wq;
-        size_t blocks = (total + 255) / 256;
-        if (blocks > 16384) blocks = 16384;
-        vst_prof_scope prof(VST_KERNEL_PRESPLIT, st);
-        presplit_kernel<<<dim3((unsigned)blocks), 256, 0, st>>>(src, sp_src, B, Hq, Wq);
-        VST_RETURN_IF_LAUNCH_FAILED();
+        if (int rc0 = vst3_presplit(src, sp_src, B, H, W, stream)) return rc0;
     }
     SpArgs a{};
     a.H = Hq; a.W = Wq; a.state_img_floats = (size_t)Hq * Wq * 256;

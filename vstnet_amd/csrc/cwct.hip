@@ -1348,6 +1348,155 @@ static int apply_labels(const float* x, float* y, long L, const float* affines, 
 }
 
 
+// ================================================================================================
+// Pixel-major ("packed code") forms for N = 32.  The coupling state at the end of a photorealistic forward pass IS the
+// code z, one 32-float row per full-resolution pixel: cell (h, w) of half i holds, contiguously, the 8 pixels
+// (4h + 2i + i', 4w + 2j + j') (layout.hip, spread).  An unmasked cWCT does not care in which order the pixels come, so
+// the statistics and the affine map run on the state itself and the spread / gather copies (2 x 256 MB per frame) go away.
+// ================================================================================================
+
+// Per-workgroup shifted sums of x[L][32] (same record as cwct_stats_mfma_kernel).  A lane's MFMA operand is one float it
+// loads itself: lane (i = l & 31, h = l >> 5) of k-step t holds x[row 2t + h][channel i] - shift[i], A and B operand of
+// v_mfma_f32_32x32x2_f32 are the same register (Q += v v^T over the two rows), no LDS in the loop.
+__global__ __launch_bounds__(256) void cwct_stats_pm_kernel(const float* __restrict__ x, long L, float* __restrict__ partial,
+                                                            int px_per_wg) {
+    constexpr int N = 32, UNR = 16;
+    __shared__ float red[4][17][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ch = lane & 31, h = lane >> 5;
+    const long p_begin = (long)blockIdx.x * px_per_wg;
+    long p_end = p_begin + px_per_wg;
+    if (p_end > L) p_end = L;
+    const float shift = p_begin < L ? x[(size_t)p_begin * N + ch] : 0.f;
+    const long per_wave = px_per_wg / 4;                    // px_per_wg is a multiple of 64 (cwct_stats_groups)
+    long wb = p_begin + wave * per_wave, we = wb + per_wave;
+    if (we > p_end) we = p_end;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float asum = 0.f;
+    // two register sets: the loads of the next 32 rows are in flight during the MFMAs of the current ones.  Loads are
+    // unconditional (a predicate per load would be a branch and a wait per load): rows past the end read the last row.
+#define PM_LOAD(dst, base)                                                                            \
+    _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                                 \
+        const long row = (base) + 2 * u + h;                                                          \
+        dst[u] = x[(size_t)(row < we ? row : we - 1) * N + ch];                                       \
+    }
+#define PM_USE(src, base)                                                                             \
+    _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                                 \
+        const float d = (base) + 2 * u + h < we ? src[u] - shift : 0.f;   /* we - wb is even: pairs are in or out together */ \
+        asum += d;                                                                                    \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(d, d, acc, 0, 0, 0);                               \
+    }
+    if (wb < we) {
+        float va[UNR], vb[UNR];
+        PM_LOAD(va, wb)
+        for (long r0 = wb; r0 < we; r0 += 4 * UNR) {
+            PM_LOAD(vb, r0 + 2 * UNR)
+            __builtin_amdgcn_sched_barrier(0);
+            PM_USE(va, r0)
+            __builtin_amdgcn_sched_barrier(0);
+            PM_LOAD(va, r0 + 4 * UNR)
+            __builtin_amdgcn_sched_barrier(0);
+            PM_USE(vb, r0 + 2 * UNR)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef PM_LOAD
+#undef PM_USE
+    asum += __shfl_xor(asum, 32, 64);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    red[wave][16][lane] = asum;
+    __syncthreads();
+    float* rec = partial + (size_t)blockIdx.x * cwct_partial_stride(N);
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float q = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+            rec[4 + 2 * N + (size_t)i * N + ch] = q;
+        }
+        if (h == 0) {
+            rec[4 + ch] = shift;
+            rec[4 + N + ch] = (red[0][16][lane] + red[1][16][lane]) + (red[2][16][lane] + red[3][16][lane]);
+        }
+        if (lane == 0) rec[0] = p_end > p_begin ? (float)(p_end - p_begin) : 0.f;
+    }
+}
+
+// y[p][:] = T x[p][:] + t0 for the rows of one image's code, [2 halves][cells][8 groups][32].  One wave-tile = 32 rows:
+// D[out channel][row] on 16 v_mfma_f32_32x32x2_f32 (exact fp32); A = T (lane (i, h) of k-step t: T[i][16h + t]), B = x
+// (lane (row n, h): x[n][16h + t], i.e. 64 contiguous bytes per lane), so a lane ends with out channels 4h + 8q + {0..3},
+// q = 0..3, of its row: float4 stores, and exactly the two 8-channel groups (q = 0, 2 and q = 1, 3) of the split-plane
+// layout.  Rows of half 0 go to `planes0` (fp16 hi / lo, when given: the f16x2 inverse pass reads that half only through
+// its planes) or to out0, rows of half 1 to out1.
+__global__ __launch_bounds__(256) void cwct_apply_pm_kernel(const float* __restrict__ x, float* __restrict__ out0,
+                                                            float* __restrict__ out1, unsigned char* __restrict__ planes0,
+                                                            int Hq, int Wq, const float* __restrict__ affine, long tiles) {
+    constexpr int N = 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    float tfrag[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) tfrag[t] = affine[n * N + 16 * h + t];
+    float4 t0[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t0[q] = *(const float4*)(affine + N * N + 8 * q + 4 * h);
+    const long rows_half = (long)Hq * Wq * 8;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < tiles; tile += (long)gridDim.x * 4) {
+        const long row = tile * 32 + n;                      // a tile may straddle the halves or the end: decided per row
+        const bool valid = row < 2 * rows_half;
+        const float4* src = (const float4*)(x + (size_t)(valid ? row : 2 * rows_half - 1) * N + 16 * h);
+        const float4 b0 = src[0], b1 = src[1], b2 = src[2], b3 = src[3];
+        const float bv[16] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tfrag[t], bv[t], acc, 0, 0, 0);
+        float o[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            o[q][0] = acc[4 * q + 0] + t0[q].x; o[q][1] = acc[4 * q + 1] + t0[q].y;
+            o[q][2] = acc[4 * q + 2] + t0[q].z; o[q][3] = acc[4 * q + 3] + t0[q].w;
+        }
+        const bool half1 = row >= rows_half;
+        if (!valid) continue;
+        if (!half1 && planes0 != nullptr) {
+            const long cell = row >> 3;
+            const int g = (int)(row & 7), y = (int)(cell / Wq), xx = (int)(cell - (long)y * Wq);
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {                 // groups kg = h (q = 0, 2) and kg = 2 + h (q = 1, 3)
+                const float f8[8] = {o[pr][0], o[pr][1], o[pr][2], o[pr][3], o[pr + 2][0], o[pr + 2][1], o[pr + 2][2], o[pr + 2][3]};
+                u32x4 hi, lo;
+                split8_sp(f8, hi, lo);
+                const int cig = (g >> 1) * 8 + (g & 1) * 4 + 2 * pr + h;
+                *(u32x4*)(planes0 + sp_offset(cig, 0, y, xx, Hq, Wq)) = hi;
+                *(u32x4*)(planes0 + sp_offset(cig, 1, y, xx, Hq, Wq)) = lo;
+            }
+        } else {
+            float* dst = half1 ? out1 + (size_t)(row - rows_half) * N : out0 + (size_t)row * N;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(float4*)(dst + 8 * q + 4 * h) = make_float4(o[q][0], o[q][1], o[q][2], o[q][3]);
+        }
+    }
+}
+
+// internal (conv.hip's decode): out0 / out1 = where the transformed halves go, planes0 (nullable) = half 0 as split planes instead
+int vst3_apply_code(const float* code, float* out0, float* out1, unsigned char* planes0, int H, int W, const float* affine,
+                    void* stream) {
+    if (H < 8 || W < 8 || (H & 3) || (W & 3)) return VST_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const long tiles = ((long)H * W + 31) / 32;             // 32-row tiles over the image's H * W rows
+    long wgs = (tiles + 3) / 4;
+    if (wgs > 8192) wgs = 8192;
+    vst_prof_scope prof(VST_KERNEL_CWCT_APPLY, st);
+    cwct_apply_pm_kernel<<<dim3((unsigned)wgs), 256, 0, st>>>(code, out0, out1, planes0, H >> 2, W >> 2, affine, tiles);
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
 extern "C" {
 
 size_t vst_cwct_stats_workspace_bytes(int N, long L) {
@@ -1543,6 +1692,33 @@ int vst_cwct_apply_labels(const float* x, float* y, int N, long L, const float* 
                             : apply_labels<128, 1>(x, y, L, affines, mask, p, max_slots, st);
         default: return VST_E_SHAPE;
     }
+}
+
+size_t vst_cwct_stats_code_workspace_bytes(int H, int W) { return vst_cwct_stats_workspace_bytes(32, (long)H * W); }
+
+int vst_cwct_stats_code(const float* code, int H, int W, double* stats, void* workspace, void* stream) {
+    if (!code || !stats) return VST_E_ARG;
+    if (!workspace) return VST_E_WORKSPACE;
+    if (H < 8 || W < 8 || (H & 3) || (W & 3)) return VST_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const long L = (long)H * W;
+    const int N = 32;
+    int per;
+    const int G = cwct_stats_groups(L, &per);
+    float* partial = (float*)workspace;
+    vst_prof_scope prof(VST_KERNEL_CWCT_STATS, st);
+    cwct_stats_pm_kernel<<<G, 256, 0, st>>>(code, L, partial, per);
+    VST_RETURN_IF_LAUNCH_FAILED();
+    cwct_stats_mean_kernel<<<N / 16, 256, 0, st>>>(partial, G, N, stats, 1, 0, nullptr);
+    VST_RETURN_IF_LAUNCH_FAILED();
+    cwct_stats_cov_kernel<<<N * N / 16, 256, 0, st>>>(partial, G, N, stats, 1, 0, nullptr);
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
+int vst_cwct_apply_code(const float* code, float* out, int H, int W, const float* affine, void* stream) {
+    if (!code || !out || !affine) return VST_E_ARG;
+    return vst3_apply_code(code, out, out + (size_t)H * W * 16, nullptr, H, W, affine, stream);
 }
 
 }  // extern "C"

@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .code import PackedCode
 
 _SUPPORTED_N = (16, 32, 64, 128)
 
@@ -97,6 +98,22 @@ class cWCT(nn.Module):
                        "vst_cwct_stats")
         return out
 
+    def stats_code(self, z, b):
+        """stats() of image b of a PackedCode (N = 32, all pixels), on the packed rows (vst_cwct_stats_code)."""
+        rows = z.applied()[b]
+        H, W = z.shape[2], z.shape[3]
+        L = _lib.lib()
+        out = torch.empty(1 + 32 + 32 * 32, dtype=torch.float64, device=rows.device)
+        ws = self._workspace(L.vst_cwct_stats_code_workspace_bytes(H, W), rows.device)
+        with torch.cuda.device(rows.device):
+            _lib.check(L.vst_cwct_stats_code(_ptr(rows), H, W, _ptr(out), _ptr(ws), _stream_ptr()), "vst_cwct_stats_code")
+        return out
+
+    @staticmethod
+    def _is_packed(x):
+        """A photorealistic code still in the coupling blocks' layout, no cWCT pending on it (code.py)."""
+        return isinstance(x, PackedCode) and x.pending_affines is None
+
     def factor(self, content_stats, style_stats_list, alphas, alpha_c, N, min_tries=None):
         """{T, t0} with T = (sum_i a_i chol(Cs_i) [blended with chol(Cc)]) * chol(Cc)^-1.  min_tries: device int32
         [2+n_styles] jitter retries to start from (the batch coupling of `interpolation`)."""
@@ -146,13 +163,14 @@ class cWCT(nn.Module):
         assert len(styl_feat_list) == len(alpha_s_list)
         B, N, cH, cW = content_feat.shape
         in_dtype = content_feat.dtype
-        c = self._prep(content_feat).reshape(B, N, -1)
+        packed = self._is_packed(content_feat)     # statistics on the packed rows; the map is applied by the inverse pass
+        c = None if packed else self._prep(content_feat).reshape(B, N, -1)
         styles = []
         for sf in styl_feat_list:
             assert sf.shape[0] == B and sf.shape[1] == N
-            styles.append(self._prep(sf).reshape(B, N, -1))
-        out = torch.empty_like(c)
-        stats = [(self.stats(c[b]), [self.stats(s[b]) for s in styles]) for b in range(B)]
+            styles.append(sf if isinstance(sf, PackedCode) else self._prep(sf).reshape(B, N, -1))
+        one = lambda t, b: self.stats_code(t, b) if isinstance(t, PackedCode) else self.stats(t[b])      # noqa: E731
+        stats = [(one(content_feat, b) if packed else self.stats(c[b]), [one(s, b) for s in styles]) for b in range(B)]
         affines, infos = [], []
         for cs, ss in stats:
             affines.append(self.factor(cs, ss, alpha_s_list, alpha_c, N))
@@ -163,6 +181,9 @@ class cWCT(nn.Module):
             need = torch.stack(infos).max(dim=0).values
             need[1] = 0
             affines = [self.factor(cs, ss, alpha_s_list, alpha_c, N, min_tries=need) for cs, ss in stats]
+        if packed:
+            return content_feat.with_affines(torch.stack(affines))
+        out = torch.empty_like(c)
         for b in range(B):
             self.apply(c[b], affines[b], out=out[b])
         return out.to(in_dtype).reshape(B, N, cH, cW)
@@ -173,10 +194,11 @@ class cWCT(nn.Module):
         re-encodes and re-factors the style for every frame (video_transfer.py:195); a video loop can
         compute this once per style and call transfer_with_stats per frame."""
         B, N = style_feat.shape[:2]
-        s = self._prep(style_feat).reshape(B, N, -1)
+        packed = isinstance(style_feat, PackedCode)
+        s = None if packed else self._prep(style_feat).reshape(B, N, -1)
         out = []
         for b in range(B):
-            st = self.stats(s[b])
+            st = self.stats_code(style_feat, b) if packed else self.stats(s[b])
             info = torch.zeros(1, dtype=torch.int32, device=st.device)
             with torch.cuda.device(st.device):       # Cholesky once per style, in place
                 _lib.check(_lib.lib().vst_cwct_prefactor(_ptr(st), N, float(self.eps), _ptr(st), _ptr(info), _stream_ptr()),
@@ -189,9 +211,13 @@ class cWCT(nn.Module):
         overwrites a contiguous fp32 content code instead of allocating the result (like the reference's masked path,
         cWCT.py:62,103; one 128 MiB buffer less per 1024x1024 frame in flight)."""
         B, N, cH, cW = content_feat.shape
+        if self._is_packed(content_feat):          # packed rows: nothing is written here, the inverse pass applies the map
+            affines = [self.factor(self.stats_code(content_feat, b), [style_stats[b if len(style_stats) > 1 else 0]], [1.0],
+                                   alpha_c, N) for b in range(B)]
+            return content_feat.with_affines(torch.stack(affines))
         in_dtype = content_feat.dtype
         c = self._prep(content_feat).reshape(B, N, -1)
-        out = c if inplace and c.data_ptr() == content_feat.data_ptr() else torch.empty_like(c)
+        out = c if inplace and not isinstance(content_feat, PackedCode) and c.data_ptr() == content_feat.data_ptr() else torch.empty_like(c)
         for b in range(B):
             ss = style_stats[b if len(style_stats) > 1 else 0]
             affine = self.factor(self.stats(c[b]), [ss], [1.0], alpha_c, N)
@@ -297,7 +323,7 @@ class cWCT(nn.Module):
             if style_feat is None or tuple(style_feat.shape) != plan.shapes[1]:
                 raise ValueError("transfer_with_plan needs the style code the plan was made for (or bind_style first)")
             s = self._prep(style_feat).reshape(B, N, -1)
-        out = c if inplace and c.data_ptr() == content_feat.data_ptr() else torch.empty_like(c)
+        out = c if inplace and not isinstance(content_feat, PackedCode) and c.data_ptr() == content_feat.data_ptr() else torch.empty_like(c)
         L = _lib.lib()
         ms = int(plan.max_slots)
         for b in range(B):

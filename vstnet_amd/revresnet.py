@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .code import PackedCode
 from .synth import STACK, CONV_IDX
 
 _PRECISIONS = {"bf16x3": _lib.PREC_BF16X3, "fp32": _lib.PREC_FP32, "f16x2": _lib.PREC_F16X2}
@@ -81,6 +82,9 @@ class RevResNet(nn.Module):
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
         self.precision = precision
+        # photorealistic mode: net(x) returns the code as a PackedCode (code.py: [B,32,H,W] to every caller, kept in the
+        # coupling blocks' own layout for cWCT and the inverse pass); False or VST_PACKED_CODE=0: always plain NCHW
+        self.packed_code = os.environ.get("VST_PACKED_CODE", "1") != "0"
         self._packed = None          # (device, blob tensor, bias tensors, NetWeights struct, parameter versions)
         self._workspace = None
         # a PARENT module's load_state_dict never calls this module's load_state_dict: invalidate through the hook as well
@@ -177,6 +181,14 @@ class RevResNet(nn.Module):
         L = _lib.lib()
         net = self._ensure_packed(x.device)
         s = self.sp_steps
+        if s == 2 and self.packed_code:          # photorealistic mode: the code stays in the blocks' layout (code.py)
+            code = torch.empty((B, 32 * H * W), dtype=torch.float32, device=x.device)
+            ws = self._get_workspace(L.vst_pass_workspace_bytes(1, H, W), x.device)
+            with torch.cuda.device(x.device):
+                _lib.check(L.vst_revnet_encode(C.byref(net), C.c_void_p(x.data_ptr()), C.c_void_p(code.data_ptr()),
+                                               C.c_void_p(ws.data_ptr()), B, self.in_channel, H, W,
+                                               _PRECISIONS[self.precision], _stream_ptr()), "vst_revnet_encode")
+            return PackedCode(code, H, W)
         z = torch.empty((B, 32, H, W) if s == 2 else (B, 128, H // 2, W // 2), dtype=torch.float32, device=x.device)
         ws = self._get_workspace(L.vst_pass_workspace_bytes(B, H, W), x.device)
         with torch.cuda.device(x.device):
@@ -188,6 +200,8 @@ class RevResNet(nn.Module):
     def _inverse(self, z):
         """models/RevResNet.py:225-239."""
         s = self.sp_steps
+        if isinstance(z, PackedCode) and s == 2:
+            return self._decode_packed(z, u8=False)
         z = self._check(z, 32 if s == 2 else 128, "RevResNet inverse input")
         B = z.shape[0]
         H, W = (z.shape[2], z.shape[3]) if s == 2 else (z.shape[2] * 2, z.shape[3] * 2)
@@ -202,6 +216,32 @@ class RevResNet(nn.Module):
                                             C.c_void_p(ws.data_ptr()), B, self.in_channel, H, W, s,
                                             _PRECISIONS[self.precision], _stream_ptr()), "vst_revnet_inverse")
         return x
+
+    def _decode_packed(self, z, u8):
+        """Inverse pass straight from the packed rows; a pending cWCT affine map is applied while the state is loaded."""
+        code, aff = z.packed, z.pending_affines
+        if not code.is_cuda:
+            raise RuntimeError("vstnet_amd.RevResNet runs on ROCm devices only (no CPU fallback)")
+        B = code.shape[0]
+        H, W = z.shape[2], z.shape[3]
+        L = _lib.lib()
+        net = self._ensure_packed(code.device)
+        out = torch.empty((B, H, W, 3) if u8 else (B, self.in_channel, H, W), dtype=torch.uint8 if u8 else torch.float32,
+                          device=code.device)
+        if u8 and self.in_channel != 3:
+            raise RuntimeError("inverse_u8 needs in_channel == 3")
+        ws = self._get_workspace(L.vst_pass_workspace_bytes(1, H, W), code.device)
+        aptr = C.c_void_p(aff.data_ptr()) if aff is not None else C.c_void_p(0)
+        with torch.cuda.device(code.device):
+            if u8:
+                _lib.check(L.vst_revnet_decode_u8(C.byref(net), C.c_void_p(code.data_ptr()), aptr, C.c_void_p(out.data_ptr()),
+                                                  C.c_void_p(ws.data_ptr()), B, H, W, _PRECISIONS[self.precision],
+                                                  _stream_ptr()), "vst_revnet_decode_u8")
+            else:
+                _lib.check(L.vst_revnet_decode(C.byref(net), C.c_void_p(code.data_ptr()), aptr, C.c_void_p(out.data_ptr()),
+                                               C.c_void_p(ws.data_ptr()), B, self.in_channel, H, W,
+                                               _PRECISIONS[self.precision], _stream_ptr()), "vst_revnet_decode")
+        return out
 
     # ------------------------------------------------------------------ uint8 frame edge (SURVEY 8(f) rank 1)
     def forward_u8(self, frames):
@@ -218,6 +258,14 @@ class RevResNet(nn.Module):
         L = _lib.lib()
         net = self._ensure_packed(frames.device)
         s = self.sp_steps
+        if s == 2 and self.packed_code:
+            code = torch.empty((B, 32 * H * W), dtype=torch.float32, device=frames.device)
+            ws = self._get_workspace(L.vst_pass_workspace_bytes(1, H, W), frames.device)
+            with torch.cuda.device(frames.device):
+                _lib.check(L.vst_revnet_encode_u8(C.byref(net), C.c_void_p(frames.data_ptr()), C.c_void_p(code.data_ptr()),
+                                                  C.c_void_p(ws.data_ptr()), B, H, W, _PRECISIONS[self.precision],
+                                                  _stream_ptr()), "vst_revnet_encode_u8")
+            return PackedCode(code, H, W)
         z = torch.empty((B, 32, H, W) if s == 2 else (B, 128, H // 2, W // 2), dtype=torch.float32, device=frames.device)
         ws = self._get_workspace(L.vst_pass_workspace_bytes(B, H, W), frames.device)
         with torch.cuda.device(frames.device):
@@ -230,6 +278,8 @@ class RevResNet(nn.Module):
         """Decode a code to uint8 HWC frames with the reference's quantisation: mul(255).clamp(0,255).byte()
         (truncation; image_transfer.py:217-218, video_transfer.py:212) fused into the last boundary kernel."""
         s = self.sp_steps
+        if isinstance(z, PackedCode) and s == 2:
+            return self._decode_packed(z, u8=True)
         z = self._check(z, 32 if s == 2 else 128, "RevResNet inverse input")
         B = z.shape[0]
         H, W = (z.shape[2], z.shape[3]) if s == 2 else (z.shape[2] * 2, z.shape[3] * 2)
