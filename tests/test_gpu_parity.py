@@ -439,7 +439,8 @@ def test_cached_style_equals_transfer_and_batch2_masked():
     got = cw.transfer_with_stats(zc, cw.style_stats(zs))              # prefactored style (Cholesky cached)
     assert_close(got, ref, 1e-6, "transfer_with_stats vs transfer")
     one = cw.transfer_with_stats(zc, cw.style_stats(zs[:1]))          # one style for every frame of the batch
-    assert_close(one[0], ref[0], 1e-6, "single cached style, sample 0")
+    # (zs[:1] is a dense tensor: its statistics come from the NCHW kernel, ref's from the packed-row kernel - two summation orders)
+    assert_close(one[0], ref[0], 5e-6, "single cached style, sample 0")
     # masked, batch of 2 with different masks per sample, against the oracle
     cm = np.stack([synthetic_mask(40, 56, 3, seed=7), synthetic_mask(40, 56, 4, seed=8)])
     sm = np.stack([synthetic_mask(32, 48, 3, seed=9, speck=False), synthetic_mask(32, 48, 4, seed=10, speck=False)])

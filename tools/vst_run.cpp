@@ -93,6 +93,7 @@ int main(int argc, char** argv) {
     HIP_OK(hipMalloc(&st_c, (1 + N + (size_t)N * N) * 8)); HIP_OK(hipMalloc(&st_s, (1 + N + (size_t)N * N) * 8));
     HIP_OK(hipMalloc(&info, 16)); HIP_OK(hipMalloc(&ws, wbytes));
     size_t cwb = vst_cwct_stats_workspace_bytes(N, L), cwb2 = vst_cwct_stats_workspace_bytes(N, Ls);
+    if (vst_cwct_stats_code_workspace_bytes(H, W) > cwb) cwb = vst_cwct_stats_code_workspace_bytes(H, W);
     HIP_OK(hipMalloc(&cws, cwb > cwb2 ? cwb : cwb2));
     HIP_OK(hipMemcpyAsync(d_c, content.data(), content.size(), hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(d_s, style.data(), style.size(), hipMemcpyHostToDevice, st));

@@ -1358,17 +1358,18 @@ static int apply_labels(const float* x, float* y, long L, const float* affines, 
 // Per-workgroup shifted sums of x[L][32] (same record as cwct_stats_mfma_kernel).  A lane's MFMA operand is one float it
 // loads itself: lane (i = l & 31, h = l >> 5) of k-step t holds x[row 2t + h][channel i] - shift[i], A and B operand of
 // v_mfma_f32_32x32x2_f32 are the same register (Q += v v^T over the two rows), no LDS in the loop.
-__global__ __launch_bounds__(256) void cwct_stats_pm_kernel(const float* __restrict__ x, long L, float* __restrict__ partial,
-                                                            int px_per_wg) {
-    constexpr int N = 32, UNR = 16;
-    __shared__ float red[4][17][64];
+// 16 waves per workgroup, 256 rows per wave at 1024 x 1024: at most 256 records for the combine kernel to read.
+__global__ __launch_bounds__(1024) void cwct_stats_pm_kernel(const float* __restrict__ x, long L, float* __restrict__ partial,
+                                                             int px_per_wg) {
+    constexpr int N = 32, UNR = 16, NWV = 16;
+    __shared__ float red[NWV / 2][17][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ch = lane & 31, h = lane >> 5;
     const long p_begin = (long)blockIdx.x * px_per_wg;
     long p_end = p_begin + px_per_wg;
     if (p_end > L) p_end = L;
     const float shift = p_begin < L ? x[(size_t)p_begin * N + ch] : 0.f;
-    const long per_wave = px_per_wg / 4;                    // px_per_wg is a multiple of 64 (cwct_stats_groups)
+    const long per_wave = px_per_wg / NWV;                  // px_per_wg is a multiple of 256: per_wave of 16
     long wb = p_begin + wave * per_wave, we = wb + per_wave;
     if (we > p_end) we = p_end;
     f32x16 acc;
@@ -1405,23 +1406,81 @@ __global__ __launch_bounds__(256) void cwct_stats_pm_kernel(const float* __restr
 #undef PM_LOAD
 #undef PM_USE
     asum += __shfl_xor(asum, 32, 64);
+    // fixed-order tree over the waves (8 + 4 + 2 + 1 rounds through LDS): bit-reproducible
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
-    red[wave][16][lane] = asum;
-    __syncthreads();
+    for (int half = NWV / 2; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave - half][r][lane] = acc[r];
+            red[wave - half][16][lane] = asum;
+        }
+        __syncthreads();
+        if (wave < half) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += red[wave][r][lane];
+            asum += red[wave][16][lane];
+        }
+        __syncthreads();
+    }
     float* rec = partial + (size_t)blockIdx.x * cwct_partial_stride(N);
     if (wave == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float q = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
             const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-            rec[4 + 2 * N + (size_t)i * N + ch] = q;
+            rec[4 + 2 * N + (size_t)i * N + ch] = acc[r];
         }
         if (h == 0) {
             rec[4 + ch] = shift;
-            rec[4 + N + ch] = (red[0][16][lane] + red[1][16][lane]) + (red[2][16][lane] + red[3][16][lane]);
+            rec[4 + N + ch] = asum;
         }
         if (lane == 0) rec[0] = p_end > p_begin ? (float)(p_end - p_begin) : 0.f;
+    }
+}
+
+// Mean and covariance from the per-workgroup records in ONE launch (cwct_stats_mean_kernel + cwct_stats_cov_kernel, same
+// arithmetic): workgroup = 16 covariance entries x 16 record strides; first the two means every entry needs, then the
+// Chan et al. update of its co-moment, both in fp64; the workgroups owning column 0 also write the means and the count.
+__global__ __launch_bounds__(256) void cwct_stats_finish_kernel(const float* __restrict__ partial, int G, int N,
+                                                                double* __restrict__ stats) {
+    __shared__ double sa[16][17], sb[16][17], sn[16][17];
+    const int el = threadIdx.x & 15, gl = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    const int i = e / N, j = e - i * N;
+    const size_t PS = cwct_partial_stride(N);
+    double ai = 0.0, aj = 0.0, nt = 0.0;
+#pragma unroll 4
+    for (int g = gl; g < G; g += 16) {
+        const float* rec = partial + (size_t)g * PS;
+        const double n = rec[0];
+        nt += n;
+        ai += n * (double)rec[4 + i] + (double)rec[4 + N + i];
+        aj += n * (double)rec[4 + j] + (double)rec[4 + N + j];
+    }
+    sa[gl][el] = ai; sb[gl][el] = aj; sn[gl][el] = nt;
+    __syncthreads();
+    double a2 = 0.0, b2 = 0.0, n2 = 0.0;
+    for (int k = 0; k < 16; ++k) { a2 += sa[k][el]; b2 += sb[k][el]; n2 += sn[k][el]; }
+    const double mu_i = n2 > 0.0 ? a2 / n2 : 0.0, mu_j = n2 > 0.0 ? b2 / n2 : 0.0;
+    __syncthreads();
+    double m2 = 0.0;
+#pragma unroll 4
+    for (int g = gl; g < G; g += 16) {
+        const float* rec = partial + (size_t)g * PS;
+        const float nf = rec[0], aif = rec[4 + N + i], ajf = rec[4 + N + j], si = rec[4 + i], sj = rec[4 + j], q = rec[4 + 2 * N + e];
+        const double n = nf, pi = aif, pj = ajf;
+        const double rn = nf > 0.f ? 1.0 / n : 0.0;
+        const double di = (double)si + pi * rn - mu_i;
+        const double dj = (double)sj + pj * rn - mu_j;
+        m2 += nf > 0.f ? (double)q - pi * pj * rn + n * di * dj : 0.0;
+    }
+    sa[gl][el] = m2;
+    __syncthreads();
+    if (gl == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += sa[k][el];
+        stats[1 + N + e] = t / (n2 - 1.0);
+        if (j == 0) stats[1 + i] = mu_i;
+        if (e == 0) stats[0] = n2;
     }
 }
 
@@ -1694,7 +1753,10 @@ int vst_cwct_apply_labels(const float* x, float* y, int N, long L, const float* 
     }
 }
 
-size_t vst_cwct_stats_code_workspace_bytes(int H, int W) { return vst_cwct_stats_workspace_bytes(32, (long)H * W); }
+size_t vst_cwct_stats_code_workspace_bytes(int H, int W) {
+    (void)H; (void)W;
+    return (size_t)256 * cwct_partial_stride(32) * sizeof(float);      // at most 256 workgroup records
+}
 
 int vst_cwct_stats_code(const float* code, int H, int W, double* stats, void* workspace, void* stream) {
     if (!code || !stats) return VST_E_ARG;
@@ -1703,15 +1765,16 @@ int vst_cwct_stats_code(const float* code, int H, int W, double* stats, void* wo
     hipStream_t st = (hipStream_t)stream;
     const long L = (long)H * W;
     const int N = 32;
-    int per;
-    const int G = cwct_stats_groups(L, &per);
-    float* partial = (float*)workspace;
-    vst_prof_scope prof(VST_KERNEL_CWCT_STATS, st);
-    cwct_stats_pm_kernel<<<G, 256, 0, st>>>(code, L, partial, per);
-    VST_RETURN_IF_LAUNCH_FAILED();
-    cwct_stats_mean_kernel<<<N / 16, 256, 0, st>>>(partial, G, N, stats, 1, 0, nullptr);
-    VST_RETURN_IF_LAUNCH_FAILED();
-    cwct_stats_cov_kernel<<<N * N / 16, 256, 0, st>>>(partial, G, N, stats, 1, 0, nullptr);
+    long per = ((L + 255) / 256 + 255) / 256 * 256;         // <= 256 workgroups of 16 waves, rows per workgroup a multiple of 256
+    const int G = (int)((L + per - 1) / per);
+    float* partial = (float*)workspace;                      // G <= 256 records: inside vst_cwct_stats_code_workspace_bytes
+    {
+        vst_prof_scope prof(VST_KERNEL_CWCT_STATS, st);
+        cwct_stats_pm_kernel<<<G, 1024, 0, st>>>(code, L, partial, (int)per);
+        VST_RETURN_IF_LAUNCH_FAILED();
+    }
+    vst_prof_scope prof(VST_KERNEL_CWCT_FACTOR, st);
+    cwct_stats_finish_kernel<<<N * N / 16, 256, 0, st>>>(partial, G, N, stats);
     VST_RETURN_IF_LAUNCH_FAILED();
     return VST_OK;
 }
