@@ -337,7 +337,10 @@ def roofline_from_table(table, n_frames, fpg, H, W, args, _lib):
     # algorithmic bytes per frame: 192 B per full-res pixel and block, 396 B glue per pass, 384 B cWCT
     blocks = {"stage1": 10 + 10 - 1, "stage2": 20, "stage3": 24}          # forward block 0 is folded into the input packing
     stage_bytes = {k: v * 192.0 * px for k, v in blocks.items()}
-    stage_bytes["glue"] = 2 * 396.0 * px
+    # glue: 396 B per pixel and pass with the spread / gather copies; 140 without them (packed code: only the
+    # RGB <-> state boundary kernels remain)
+    has_spread = any(_lib.MISC_KERNELS.get(kid, "") in ("spread", "gather") for kid in table if kid < 65536)
+    stage_bytes["glue"] = 2 * (396.0 if has_spread else 140.0) * px
     stage_bytes["cwct"] = 384.0 * px
     stages = {}
     for k, m in stage_ms.items():

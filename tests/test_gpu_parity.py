@@ -876,6 +876,7 @@ def test_packed_code_equals_dense_path(precision):
     from models.cWCT import cWCT
     from vstnet_amd.code import PackedCode, from_dense
     net, sd, sp = make_net("photo", precision)
+    net.packed_code = "always"                  # (by default batches of small images keep the dense, batched passes)
     dense, _, _ = make_net("photo", precision)
     dense.packed_code = False
     cw = cWCT(precision=precision)
@@ -906,6 +907,10 @@ def test_packed_code_equals_dense_path(precision):
             again = cw.transfer(t, zs)
             assert not isinstance(again, PackedCode)
             assert_close(again, cw.transfer(td, zsd), 2e-5, "cWCT of a cWCT result")
+    auto, _, _ = make_net("photo", precision)
+    with torch.no_grad():
+        assert isinstance(auto(synthetic_frames(1, 16, 16).cuda()), PackedCode)
+        assert not isinstance(auto(synthetic_frames(3, 16, 16).cuda()), PackedCode), "small-image batches stay dense"
     # parity with the oracle through the packed path
     x, xs = synthetic_frames(1, 48, 64, seed=0), synthetic_frames(1, 48, 64, seed=1)
     with torch.no_grad():

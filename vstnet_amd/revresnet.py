@@ -83,7 +83,8 @@ class RevResNet(nn.Module):
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
         self.precision = precision
         # photorealistic mode: net(x) returns the code as a PackedCode (code.py: [B,32,H,W] to every caller, kept in the
-        # coupling blocks' own layout for cWCT and the inverse pass); False or VST_PACKED_CODE=0: always plain NCHW
+        # coupling blocks' own layout for cWCT and the inverse pass) where the passes run image by image anyway (_use_packed);
+        # "always": for every batch; False or VST_PACKED_CODE=0: always plain NCHW
         self.packed_code = os.environ.get("VST_PACKED_CODE", "1") != "0"
         self._packed = None          # (device, blob tensor, bias tensors, NetWeights struct, parameter versions)
         self._workspace = None
@@ -181,7 +182,7 @@ class RevResNet(nn.Module):
         L = _lib.lib()
         net = self._ensure_packed(x.device)
         s = self.sp_steps
-        if s == 2 and self.packed_code:          # photorealistic mode: the code stays in the blocks' layout (code.py)
+        if s == 2 and self._use_packed(B, H, W):  # photorealistic mode: the code stays in the blocks' layout (code.py)
             code = torch.empty((B, 32 * H * W), dtype=torch.float32, device=x.device)
             ws = self._get_workspace(L.vst_pass_workspace_bytes(1, H, W), x.device)
             with torch.cuda.device(x.device):
@@ -216,6 +217,14 @@ class RevResNet(nn.Module):
                                             C.c_void_p(ws.data_ptr()), B, self.in_channel, H, W, s,
                                             _PRECISIONS[self.precision], _stream_ptr()), "vst_revnet_inverse")
         return x
+
+    def _use_packed(self, B, H, W):
+        """The packed passes run one image at a time (an image's two state halves are adjacent in the code).  That is what
+        the dense passes do anyway once an image's working set reaches the cache budget (conv.hip, pass_sub_batch: 192 MiB /
+        288 B per pixel); batches of SMALL images keep the dense route, whose launches cover several images."""
+        if self.packed_code == "always":
+            return True
+        return bool(self.packed_code) and (B == 1 or (192 << 20) // (H * W * 288) <= 1)
 
     def _decode_packed(self, z, u8):
         """Inverse pass straight from the packed rows; a pending cWCT affine map is applied while the state is loaded."""
@@ -258,7 +267,7 @@ class RevResNet(nn.Module):
         L = _lib.lib()
         net = self._ensure_packed(frames.device)
         s = self.sp_steps
-        if s == 2 and self.packed_code:
+        if s == 2 and self._use_packed(B, H, W):
             code = torch.empty((B, 32 * H * W), dtype=torch.float32, device=frames.device)
             ws = self._get_workspace(L.vst_pass_workspace_bytes(1, H, W), frames.device)
             with torch.cuda.device(frames.device):
