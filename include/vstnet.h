@@ -151,6 +151,22 @@ int vst_z_to_code(const float* z, float* code, int B, int H, int W, void* stream
 size_t vst_cwct_stats_code_workspace_bytes(int H, int W);
 int vst_cwct_stats_code(const float* code, int H, int W, double* stats, void* workspace, void* stream);
 int vst_cwct_apply_code(const float* code, float* out, int H, int W, const float* affine, void* stream);
+/* Masked transfer (cWCT.py:49-109) on ONE image's packed code.  `mask_rows` = the label of every row, i.e. the [H][W] label
+ * map in the code's pixel order (vst_mask_to_code; once per mask).  plan / max_slots / affines as in the vst_cwct_*_labels
+ * calls below (vst_label_plan works on the label maps in any order); the apply and the decode take at most 8 slots
+ * (VST_E_SHAPE otherwise: use the z route), the statistics any number.  Rows whose label has no slot keep their values. */
+int vst_mask_to_code(const uint8_t* mask, uint8_t* mask_rows, int H, int W, void* stream);
+size_t vst_cwct_stats_labels_code_workspace_bytes(int H, int W);
+int vst_cwct_stats_labels_code(const float* code, int H, int W, const uint8_t* mask_rows, const void* plan, int max_slots,
+                               double* stats, void* workspace, void* stream);
+int vst_cwct_apply_labels_code(const float* code, float* out, int H, int W, const float* affines, const uint8_t* mask_rows,
+                               const void* plan, int max_slots, void* stream);
+int vst_revnet_decode_labels(const vst_net_weights* w, const float* code, const float* affines, const uint8_t* mask_rows,
+                             const void* plan, int max_slots, float* x, void* workspace, int C_out, int H, int W,
+                             int precision, void* stream);
+int vst_revnet_decode_labels_u8(const vst_net_weights* w, const float* code, const float* affines, const uint8_t* mask_rows,
+                                const void* plan, int max_slots, uint8_t* frame_hwc, void* workspace, int H, int W,
+                                int precision, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * cWCT (C-1..C-6; models/cWCT.py).  Feature matrices are x[N][L] fp32 row-major (one NCHW image:

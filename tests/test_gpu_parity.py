@@ -918,3 +918,47 @@ def test_packed_code_equals_dense_path(precision):
     zc, zs_ = cpu_ref.revnet_forward(x, sd, sp), cpu_ref.revnet_forward(xs, sd, sp)
     ref = cpu_ref.revnet_inverse(cpu_ref.transfer(zc, zs_), sd, sp)
     assert_close(got, ref, 2e-4 if precision == "f16x2" else TIGHT, "stylised frame through the packed code vs oracle")
+
+
+@pytest.mark.parametrize("kind", ["bands", "noise"])
+def test_packed_code_masked_transfer(kind):
+    """transfer_with_plan on a PackedCode: per-label statistics and per-row affine maps on the packed rows (label map
+    permuted once per plan into the rows' order), applied by the inverse pass.  Against the dense masked route, and against
+    the oracle; 3..8 labels incl. a speck (invalid label: its rows keep their values), a batch, region and per-pixel masks."""
+    from models.cWCT import cWCT
+    from vstnet_amd.code import PackedCode
+    net, sd, sp = make_net("photo", "bf16x3")
+    net.packed_code = "always"
+    dense, _, _ = make_net("photo", "bf16x3")
+    dense.packed_code = False
+    cw = cWCT(precision="fp32")                  # dense masked apply in exact fp32 too: the two routes then differ by rounding only
+    for B, H, W, K in ((1, 64, 96, 3), (2, 40, 24, 4), (1, 128, 192, 5), (1, 96, 96, 8)):
+        x, xs = synthetic_frames(B, H, W, seed=2).cuda(), synthetic_frames(B, H, W, seed=3).cuda()
+        cm = np.stack([synthetic_mask(H, W, K, seed=3 + b, kind=kind) for b in range(B)])
+        sm = np.stack([synthetic_mask(H, W, K, seed=9 + b, speck=False, kind=kind) for b in range(B)])
+        with torch.no_grad():
+            z, zd, zs = net(x), dense(x), dense(xs)
+            plan = cw.learn_slots(cw.plan_masks(cm, sm, z.shape, zs.shape, z.device))
+            t, td = cw.transfer_with_plan(z, zs, plan), cw.transfer_with_plan(zd, zs, plan)
+            assert isinstance(t, PackedCode) and t.pending_labels is not None and not isinstance(td, PackedCode)
+            # (two summation orders of the per-label statistics; small regions have ill-conditioned covariances that amplify it)
+            assert_close(t.materialize(), td, 1e-5, f"masked transfer on packed rows {kind} {B}x{H}x{W} K={K}", tol_max=1e-4)
+            assert float((net(t, forward=False) - dense(td, forward=False)).abs().max()) <= 1e-4
+            assert int((net.inverse_u8(t).int() - dense.inverse_u8(td).int()).abs().max()) <= 1
+            bound = cw.bind_style(cw.learn_slots(cw.plan_masks(cm, sm, z.shape, zs.shape, z.device)), zs)
+            assert_close(cw.transfer_with_plan(z, None, bound).materialize(), td, 1e-5, "bound style", tol_max=1e-4)
+            ref = cpu_ref.transfer_seg(zd.cpu(), zs.cpu(), cm, sm)
+        assert_close(t.materialize(), ref, 2e-4, f"masked packed transfer vs oracle {kind} K={K}", tol_max=TOL)
+    # more than 8 slots, or a plan whose slot count was never read back: the dense route takes over
+    H, W, K = 96, 128, 11
+    x, xs = synthetic_frames(1, H, W, seed=2).cuda(), synthetic_frames(1, H, W, seed=3).cuda()
+    cm = synthetic_mask(H, W, K, seed=5, kind=kind, speck=False)[None]
+    sm = synthetic_mask(H, W, K, seed=6, kind=kind, speck=False)[None]
+    with torch.no_grad():
+        z, zs = net(x), dense(xs)
+        plan = cw.plan_masks(cm, sm, z.shape, zs.shape, z.device)
+        out0 = cw.transfer_with_plan(z, zs, plan)
+        assert not isinstance(out0, PackedCode)
+        out1 = cw.transfer_with_plan(z, zs, cw.learn_slots(plan))
+        assert (not isinstance(out1, PackedCode)) == (plan.max_slots > 8)
+        assert_close(out1 if not isinstance(out1, PackedCode) else out1.materialize(), out0, 1e-5, "11 labels", tol_max=1e-4)

@@ -32,6 +32,8 @@ EXPORTS = [
     "vst_cwct_factor_labels", "vst_cwct_apply_labels", "vst_profile_begin", "vst_profile_end", "vst_profile_end_table", "vst_lab_luminance",
     "vst_revnet_encode", "vst_revnet_encode_u8", "vst_revnet_decode", "vst_revnet_decode_u8", "vst_code_to_z", "vst_z_to_code",
     "vst_cwct_stats_code_workspace_bytes", "vst_cwct_stats_code", "vst_cwct_apply_code",
+    "vst_mask_to_code", "vst_cwct_stats_labels_code_workspace_bytes", "vst_cwct_stats_labels_code", "vst_cwct_apply_labels_code",
+    "vst_revnet_decode_labels", "vst_revnet_decode_labels_u8",
 ]
 
 
@@ -133,6 +135,12 @@ def lib() -> C.CDLL:
         "vst_cwct_stats_code_workspace_bytes": (sz, [i, i]),
         "vst_cwct_stats_code": (i, [vp, i, i, vp, vp, vp]),
         "vst_cwct_apply_code": (i, [vp, vp, i, i, vp, vp]),
+        "vst_mask_to_code": (i, [vp, vp, i, i, vp]),
+        "vst_cwct_stats_labels_code_workspace_bytes": (sz, [i, i]),
+        "vst_cwct_stats_labels_code": (i, [vp, i, i, vp, vp, i, vp, vp, vp]),
+        "vst_cwct_apply_labels_code": (i, [vp, vp, i, i, vp, vp, vp, i, vp]),
+        "vst_revnet_decode_labels": (i, [C.POINTER(NetWeights), vp, vp, vp, vp, i, vp, vp, i, i, i, i, vp]),
+        "vst_revnet_decode_labels_u8": (i, [C.POINTER(NetWeights), vp, vp, vp, vp, i, vp, vp, i, i, i, vp]),
         "vst_profile_begin": (i, [i, i]),
         "vst_profile_end": (i, [C.POINTER(C.c_double), C.POINTER(i)]),
         "vst_profile_end_table": (i, [C.POINTER(i), C.POINTER(C.c_double), C.POINTER(i), i, C.POINTER(i)]),

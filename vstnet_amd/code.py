@@ -27,19 +27,23 @@ class PackedCode(torch.Tensor):
     """float[B][2][H/4][W/4][256] behind the interface of a [B,32,H,W] tensor (see the module docstring)."""
 
     @staticmethod
-    def __new__(cls, code, H, W, affines=None):
+    def __new__(cls, code, H, W, affines=None, labels=None):
         B = code.shape[0]
         r = torch.Tensor._make_wrapper_subclass(cls, (B, 32, H, W), dtype=torch.float32, device=code.device,
                                                 requires_grad=False)
         r._code = code            # flat float32 [B, 32*H*W], packed rows
         r._hw = (H, W)
         r._affines = affines      # None, or float32 [B, 32*32+32]: y = T x + t0 still to be applied to every row of image b
+        # None, or the pending MASKED cWCT: per image (affines of its label slots [slots, 1056], labels of its rows uint8
+        # [H*W], its label plan), and the slot count the launches cover
+        r._labels = labels
         r._dense = None
         return r
 
     def __repr__(self):
         H, W = self._hw
-        return f"PackedCode(B={self._code.shape[0]}, H={H}, W={W}, pending_affine={self._affines is not None})"
+        what = "affine" if self._affines is not None else ("masked" if self._labels is not None else "none")
+        return f"PackedCode(B={self._code.shape[0]}, H={H}, W={W}, pending={what})"
 
     @property
     def packed(self):
@@ -49,19 +53,33 @@ class PackedCode(torch.Tensor):
     def pending_affines(self):
         return self._affines
 
+    @property
+    def pending_labels(self):
+        return self._labels
+
+    @property
+    def pending(self):
+        return self._affines is not None or self._labels is not None
+
     def _need_gpu(self):
         if not self._code.is_cuda:
             raise RuntimeError("vstnet_amd.PackedCode lives on ROCm devices only (no CPU fallback)")
 
     def with_affines(self, affines):
         """The same packed rows with the affine map of a cWCT attached (composition is not supported: materialise first)."""
-        assert self._affines is None
+        assert not self.pending
         H, W = self._hw
         return PackedCode(self._code, H, W, affines)
 
+    def with_label_affines(self, per_image, max_slots):
+        """The same rows with a masked cWCT attached: per_image[b] = (affines [slots,1056], row labels, label plan)."""
+        assert not self.pending
+        H, W = self._hw
+        return PackedCode(self._code, H, W, None, (list(per_image), int(max_slots)))
+
     def applied(self):
         """Packed rows with the pending affine map applied (a new buffer), or the rows themselves if none is pending."""
-        if self._affines is None:
+        if not self.pending:
             return self._code
         self._need_gpu()
         L = _lib.lib()
@@ -69,8 +87,15 @@ class PackedCode(torch.Tensor):
         out = torch.empty_like(self._code)
         with torch.cuda.device(self._code.device):
             for b in range(self._code.shape[0]):
-                _lib.check(L.vst_cwct_apply_code(C.c_void_p(self._code[b].data_ptr()), C.c_void_p(out[b].data_ptr()), H, W,
-                                                 C.c_void_p(self._affines[b].data_ptr()), _stream_ptr()), "vst_cwct_apply_code")
+                if self._affines is not None:
+                    _lib.check(L.vst_cwct_apply_code(C.c_void_p(self._code[b].data_ptr()), C.c_void_p(out[b].data_ptr()), H, W,
+                                                     C.c_void_p(self._affines[b].data_ptr()), _stream_ptr()), "vst_cwct_apply_code")
+                else:
+                    aff, rows, plan = self._labels[0][b]
+                    _lib.check(L.vst_cwct_apply_labels_code(C.c_void_p(self._code[b].data_ptr()), C.c_void_p(out[b].data_ptr()),
+                                                            H, W, C.c_void_p(aff.data_ptr()), C.c_void_p(rows.data_ptr()),
+                                                            C.c_void_p(plan.data_ptr()), self._labels[1], _stream_ptr()),
+                               "vst_cwct_apply_labels_code")
         return out
 
     def materialize(self):

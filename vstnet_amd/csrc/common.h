@@ -142,6 +142,9 @@ int vst3_presplit(const float* state, unsigned char* planes, int B, int H, int W
 int vst3_apply_code(const float* code, float* out0, float* out1, unsigned char* planes0, int H, int W, const float* affine,
                     void* stream);
 
+int vst3_apply_labels_code(const float* code, float* out0, float* out1, unsigned char* planes0, int H, int W,
+                           const float* affines, const uint8_t* mask_rows, const void* plan, int max_slots, void* stream);
+
 // internal (not part of the C ABI): input packing with the constant of forward block 0 folded in
 extern "C" int vst_pack_input_k(const float* x, const uint8_t* x_u8, float* s1, float* s2, int B, int C, int H, int W,
                                 const float* addk, void* stream);

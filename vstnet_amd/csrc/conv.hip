@@ -1238,6 +1238,22 @@ static int revnet_encode_any(const vst_net_weights* w, const float* x, const uin
     return VST_OK;
 }
 
+// one image whose cWCT is a masked one: a map per row (label slot), cwct.hip: vst3_apply_labels_code
+static int revnet_decode_labels_any(const vst_net_weights* w, const float* code, const float* affines, const uint8_t* mask_rows,
+                                    const void* plan, int max_slots, float* x, uint8_t* x_u8, void* workspace, int C_out, int H,
+                                    int W, int precision, void* stream) {
+    if (!w || (!x && !x_u8) || !code || !affines || !mask_rows || !plan) return VST_E_ARG;
+    if (!workspace) return VST_E_WORKSPACE;
+    if (!vst_shape_ok(1, H, W) || C_out < 1 || C_out > 16 || max_slots < 1 || max_slots > 8) return VST_E_SHAPE;
+    const size_t img = (size_t)32 * H * W;
+    float* s[2] = {(float*)workspace, (float*)workspace + img / 2};
+    float* tmp = (float*)workspace + img;
+    unsigned char* planes0 = precision == VST_PREC_F16X2 ? vst3_plane_buffer(tmp, 0, 1, H, W) : nullptr;
+    int rc = vst3_apply_labels_code(code, s[0], s[1], planes0, H, W, affines, mask_rows, plan, max_slots, stream);
+    if (rc) return rc;
+    return inverse_blocks(w, x, x_u8, s, tmp, 1, C_out, H, W, precision, stream);
+}
+
 static int revnet_decode_any(const vst_net_weights* w, const float* code, const float* affines, float* x, uint8_t* x_u8,
                              void* workspace, int B, int C_out, int H, int W, int precision, void* stream) {
     if (!w || (!x && !x_u8) || !code) return VST_E_ARG;
@@ -1349,6 +1365,22 @@ int vst_revnet_decode_u8(const vst_net_weights* w, const float* code, const floa
                          int B, int H, int W, int precision, void* stream) {
     if (!frames_hwc) return VST_E_ARG;
     return revnet_decode_any(w, code, affines, nullptr, frames_hwc, workspace, B, 3, H, W, precision, stream);
+}
+
+int vst_revnet_decode_labels(const vst_net_weights* w, const float* code, const float* affines, const uint8_t* mask_rows,
+                             const void* plan, int max_slots, float* x, void* workspace, int C_out, int H, int W, int precision,
+                             void* stream) {
+    if (!x) return VST_E_ARG;
+    return revnet_decode_labels_any(w, code, affines, mask_rows, plan, max_slots, x, nullptr, workspace, C_out, H, W, precision,
+                                    stream);
+}
+
+int vst_revnet_decode_labels_u8(const vst_net_weights* w, const float* code, const float* affines, const uint8_t* mask_rows,
+                                const void* plan, int max_slots, uint8_t* frame_hwc, void* workspace, int H, int W, int precision,
+                                void* stream) {
+    if (!frame_hwc) return VST_E_ARG;
+    return revnet_decode_labels_any(w, code, affines, mask_rows, plan, max_slots, nullptr, frame_hwc, workspace, 3, H, W,
+                                    precision, stream);
 }
 
 int vst_code_to_z(const float* code, float* z, int B, int H, int W, void* stream) {

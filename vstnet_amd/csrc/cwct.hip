@@ -1542,6 +1542,246 @@ __global__ __launch_bounds__(256) void cwct_apply_pm_kernel(const float* __restr
     }
 }
 
+// ---- masked forms on the packed rows -------------------------------------------------------------------------------------
+// The label of row r of an image's code: rows are (half i, cell (h, w), group g = 4j + 2i' + j') <-> pixel (4h + 2i + i', 4w + 2j + j')
+__global__ __launch_bounds__(256) void mask_to_code_kernel(const uint8_t* __restrict__ mask, uint8_t* __restrict__ out, int H, int W) {
+    const int Hq = H >> 2, Wq = W >> 2;
+    const long rows_half = (long)Hq * Wq * 8, total = 2 * rows_half;
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < total; r += (long)gridDim.x * 256) {
+        const int i = r >= rows_half;
+        const long rr = r - i * rows_half;
+        const long cell = rr >> 3;
+        const int g = (int)(rr & 7), h = (int)(cell / Wq), w = (int)(cell - (long)h * Wq);
+        const int y = 4 * h + 2 * i + ((g >> 1) & 1), x = 4 * w + 2 * (g >> 2) + (g & 1);
+        out[r] = mask[(size_t)y * W + x];
+    }
+}
+
+// Rows of a wave's 256-row window, bucketed by label slot: bucket[k][0 .. count[k]) = offsets (0..255) of the rows of slot k
+// in ascending order; rows of no slot go to bucket NB - 1 when `keep_rest`, else nowhere.  Lane l owns rows l, l + 64, ...;
+// ranks come from ballots + popcounts (NB x 4 of them per window), the bucket arrays are the wave's own LDS.
+template <int NB>
+__device__ __forceinline__ void bucket_rows(const uint8_t* __restrict__ mrow, long wbase, long wend, const unsigned char* lut,
+                                            int slot0, int n_take, bool keep_rest, unsigned char (*bucket)[256], int* count) {
+    const int lane = threadIdx.x & 63;
+    int rel[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long row = wbase + lane + 64 * i;
+        int r = -1;
+        if (row < wend) {
+            const int sl = lut[mrow[row]];
+            r = (sl != 255 && sl >= slot0 && sl < slot0 + n_take) ? sl - slot0 : (keep_rest ? NB - 1 : -1);
+        }
+        rel[i] = r;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        int run = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned long long bal = __ballot(rel[i] == k);
+            if (rel[i] == k) bucket[k][run + __popcll(bal & lt)] = (unsigned char)(lane + 64 * i);
+            run += __popcll(bal);
+        }
+        count[k] = run;                                      // wave-uniform
+    }
+}
+
+// cwct_stats_pm_kernel for up to 8 label slots [slot0, slot0 + 8) in one pass over the rows.  Each wave buckets its rows by
+// slot, 256 at a time; slot k's rows then feed accumulator set k two per MFMA, fetched in bucket order (a lane's operand is
+// still one float it loads itself: which row is free) - about one window's worth of MFMAs per window however the labels are
+// mixed.  8 waves per workgroup, records (workgroup, slot) as cwct_stats_labels_kernel writes them.
+__global__ __launch_bounds__(512) void cwct_stats_labels_pm_kernel(const float* __restrict__ x, long L,
+                                                                   const uint8_t* __restrict__ mrow,
+                                                                   const LabelPlan* __restrict__ plan, int slot0,
+                                                                   float* __restrict__ partial, int px_per_wg) {
+    constexpr int N = 32, UNR = 16, NWV = 8, KRES = 8;
+    __shared__ float red[NWV / 2][18][64];
+    __shared__ unsigned char lut[256];
+    __shared__ unsigned char buckets[NWV][KRES][256];
+    if (slot0 >= plan->n_slots) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ch = lane & 31, h = lane >> 5;
+    if (tid < 256) lut[tid] = plan->lut[tid];
+    const long p_begin = (long)blockIdx.x * px_per_wg;
+    long p_end = p_begin + px_per_wg;
+    if (p_end > L) p_end = L;
+    const float shift = p_begin < L ? x[(size_t)p_begin * N + ch] : 0.f;
+    const long per_wave = px_per_wg / NWV;
+    long wb = p_begin + wave * per_wave, we = wb + per_wave;
+    if (we > p_end) we = p_end;
+    f32x16 acc[KRES];
+    float asum[KRES], cnt[KRES];
+#pragma unroll
+    for (int k = 0; k < KRES; ++k) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+        asum[k] = 0.f; cnt[k] = 0.f;
+    }
+    __syncthreads();
+    unsigned char (*bk)[256] = buckets[wave];
+    for (long w0 = wb; w0 < we; w0 += 256) {
+        int count[KRES];
+        bucket_rows<KRES>(mrow, w0, we, lut, slot0, KRES, false, bk, count);
+        __builtin_amdgcn_wave_barrier();                     // the wave's own LDS writes, before its reads below
+#pragma unroll
+        for (int k = 0; k < KRES; ++k) {
+            const int nk = count[k];
+            cnt[k] += (float)nk;                             // (every lane: the same number)
+            for (int q0 = 0; q0 < nk; q0 += 2 * UNR) {       // 32 bucket positions = 16 MFMAs
+                float v[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int q = q0 + 2 * u + h;
+                    v[u] = x[(size_t)(w0 + bk[k][q < nk ? q : nk - 1]) * N + ch];
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    if (q0 + 2 * u < nk) {                   // uniform; an odd run's last pair has a zero partner
+                        const float d = q0 + 2 * u + h < nk ? v[u] - shift : 0.f;
+                        asum[k] += d;
+                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(d, d, acc[k], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // per slot: fixed-order tree over the 8 waves, then one record
+#pragma unroll
+    for (int k = 0; k < KRES; ++k) {
+        float as = asum[k] + __shfl_xor(asum[k], 32, 64), cn = cnt[k];
+#pragma unroll
+        for (int half = NWV / 2; half >= 1; half >>= 1) {
+            if (wave >= half && wave < 2 * half) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[wave - half][r][lane] = acc[k][r];
+                red[wave - half][16][lane] = as;
+                red[wave - half][17][lane] = cn;
+            }
+            __syncthreads();
+            if (wave < half) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[k][r] += red[wave][r][lane];
+                as += red[wave][16][lane];
+                cn += red[wave][17][lane];
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+            float* rec = partial + ((size_t)blockIdx.x * KRES + k) * cwct_partial_stride(N);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rec[4 + 2 * N + (size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * N + ch] = acc[k][r];
+            if (h == 0) {
+                rec[4 + ch] = shift;
+                rec[4 + N + ch] = as;
+            }
+            if (lane == 0) rec[0] = cn;
+        }
+    }
+}
+
+// cwct_apply_pm_kernel with a map per row: y = T[slot(row)] x + t0[slot(row)] for up to 8 slots; rows of no slot keep x (the
+// identity is the ninth "slot": exact on the fp32 MFMA).  A wave buckets 256 rows by slot and then runs 32-row tiles of ONE
+// slot each (which rows form a tile is free: every lane loads and stores its own row), so the MFMA work is that of the unmasked
+// kernel plus one partial tile per slot and window, however the labels are mixed.  T's fragments sit in LDS in lane order.
+__global__ __launch_bounds__(256) void cwct_apply_labels_pm_kernel(const float* __restrict__ x, float* __restrict__ out0,
+                                                                   float* __restrict__ out1, unsigned char* __restrict__ planes0,
+                                                                   int Hq, int Wq, const float* __restrict__ affines,
+                                                                   const uint8_t* __restrict__ mrow,
+                                                                   const LabelPlan* __restrict__ plan, long windows,
+                                                                   int max_slots) {
+    constexpr int N = 32, KA = 8;
+    extern __shared__ __attribute__((aligned(16))) float tl_dyn[];      // [max_slots][16][64]: only the slots in use
+    float (*tl)[16][64] = (float (*)[16][64])tl_dyn;
+    __shared__ __attribute__((aligned(16))) float t0s[KA + 1][N];
+    __shared__ unsigned char lut[256];
+    __shared__ unsigned char buckets[4][KA + 1][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const int n_slots = plan->n_slots < max_slots ? plan->n_slots : max_slots;
+    for (int idx = tid; idx < max_slots * 16 * 64; idx += 256) {
+        const int k = idx >> 10, t = (idx >> 6) & 15, l = idx & 63;
+        tl[k][t][l] = k < n_slots ? affines[(size_t)k * (N * N + N) + (l & 31) * N + 16 * (l >> 5) + t] : 0.f;
+    }
+    for (int idx = tid; idx < (KA + 1) * N; idx += 256) {
+        const int k = idx / N;
+        t0s[k][idx - k * N] = k < n_slots ? affines[(size_t)k * (N * N + N) + N * N + (idx - k * N)] : 0.f;
+    }
+    lut[tid] = plan->lut[tid];
+    __syncthreads();
+    const long rows_half = (long)Hq * Wq * 8, total = 2 * rows_half;
+    unsigned char (*bk)[256] = buckets[wave];
+    for (long win = (long)blockIdx.x * 4 + wave; win < windows; win += (long)gridDim.x * 4) {
+        const long w0 = win * 256;
+        int count[KA + 1];
+        bucket_rows<KA + 1>(mrow, w0, total, lut, 0, n_slots, true, bk, count);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k <= KA; ++k) {
+            const int nk = count[k];                         // (0 for every slot >= n_slots: their fragments are never read)
+            for (int q0 = 0; q0 < nk; q0 += 32) {
+                const bool valid = q0 + n < nk;
+                const long row = w0 + bk[k][valid ? q0 + n : nk - 1];
+                const float4* src = (const float4*)(x + (size_t)row * N + 16 * h);
+                const float4 b0 = src[0], b1 = src[1], b2 = src[2], b3 = src[3];
+                const float bv[16] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const float a = k < KA ? tl[k < KA ? k : 0][t][lane] : (n == 16 * h + t ? 1.f : 0.f);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[t], acc, 0, 0, 0);
+                }
+                float o[4][4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 tq = *(const float4*)&t0s[k][8 * q + 4 * h];
+                    o[q][0] = acc[4 * q + 0] + tq.x; o[q][1] = acc[4 * q + 1] + tq.y;
+                    o[q][2] = acc[4 * q + 2] + tq.z; o[q][3] = acc[4 * q + 3] + tq.w;
+                }
+                if (!valid) continue;
+                const bool half1 = row >= rows_half;
+                if (!half1 && planes0 != nullptr) {
+                    const long cell = row >> 3;
+                    const int g = (int)(row & 7), y = (int)(cell / Wq), xx = (int)(cell - (long)y * Wq);
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const float f8[8] = {o[pr][0], o[pr][1], o[pr][2], o[pr][3], o[pr + 2][0], o[pr + 2][1], o[pr + 2][2], o[pr + 2][3]};
+                        u32x4 hi, lo;
+                        split8_sp(f8, hi, lo);
+                        const int cig = (g >> 1) * 8 + (g & 1) * 4 + 2 * pr + h;
+                        *(u32x4*)(planes0 + sp_offset(cig, 0, y, xx, Hq, Wq)) = hi;
+                        *(u32x4*)(planes0 + sp_offset(cig, 1, y, xx, Hq, Wq)) = lo;
+                    }
+                } else {
+                    float* dst = half1 ? out1 + (size_t)(row - rows_half) * N : out0 + (size_t)row * N;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *(float4*)(dst + 8 * q + 4 * h) = make_float4(o[q][0], o[q][1], o[q][2], o[q][3]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int vst3_apply_labels_code(const float* code, float* out0, float* out1, unsigned char* planes0, int H, int W,
+                           const float* affines, const uint8_t* mask_rows, const void* plan, int max_slots, void* stream) {
+    if (H < 8 || W < 8 || (H & 3) || (W & 3) || max_slots < 1 || max_slots > 8) return VST_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const long windows = ((long)H * W + 255) / 256;         // 256-row windows, one per wave at a time
+    long wgs = (windows + 3) / 4;
+    if (wgs > 4096) wgs = 4096;
+    vst_prof_scope prof(VST_KERNEL_CWCT_APPLY, st);
+    cwct_apply_labels_pm_kernel<<<dim3((unsigned)wgs), 256, (size_t)max_slots * 4096, st>>>(
+        code, out0, out1, planes0, H >> 2, W >> 2, affines, mask_rows, (const LabelPlan*)plan, windows, max_slots);
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
 // internal (conv.hip's decode): out0 / out1 = where the transformed halves go, planes0 (nullable) = half 0 as split planes instead
 int vst3_apply_code(const float* code, float* out0, float* out1, unsigned char* planes0, int H, int W, const float* affine,
                     void* stream) {
@@ -1782,6 +2022,52 @@ int vst_cwct_stats_code(const float* code, int H, int W, double* stats, void* wo
 int vst_cwct_apply_code(const float* code, float* out, int H, int W, const float* affine, void* stream) {
     if (!code || !out || !affine) return VST_E_ARG;
     return vst3_apply_code(code, out, out + (size_t)H * W * 16, nullptr, H, W, affine, stream);
+}
+
+int vst_mask_to_code(const uint8_t* mask, uint8_t* mask_rows, int H, int W, void* stream) {
+    if (!mask || !mask_rows) return VST_E_ARG;
+    if (H < 8 || W < 8 || (H & 3) || (W & 3)) return VST_E_SHAPE;
+    long blocks = ((long)H * W + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    mask_to_code_kernel<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(mask, mask_rows, H, W);
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
+
+size_t vst_cwct_stats_labels_code_workspace_bytes(int H, int W) {
+    (void)H; (void)W;
+    return (size_t)512 * 8 * cwct_partial_stride(32) * sizeof(float);     // at most 512 workgroups x 8 slots per pass
+}
+
+int vst_cwct_stats_labels_code(const float* code, int H, int W, const uint8_t* mask_rows, const void* plan, int max_slots,
+                               double* stats, void* workspace, void* stream) {
+    if (!code || !mask_rows || !plan || !stats) return VST_E_ARG;
+    if (!workspace) return VST_E_WORKSPACE;
+    if (H < 8 || W < 8 || (H & 3) || (W & 3)) return VST_E_SHAPE;
+    if (max_slots <= 0 || max_slots > CWCT_MAX_SLOTS) max_slots = CWCT_MAX_SLOTS;
+    hipStream_t st = (hipStream_t)stream;
+    const long L = (long)H * W;
+    const int N = 32, KRES = 8;
+    long per = ((L + 511) / 512 + 2047) / 2048 * 2048;      // <= 512 workgroups of 8 waves, whole 256-row windows per wave
+    const int G = (int)((L + per - 1) / per);
+    float* partial = (float*)workspace;
+    const LabelPlan* p = (const LabelPlan*)plan;
+    vst_prof_scope prof(VST_KERNEL_CWCT_STATS, st);
+    for (int slot0 = 0; slot0 < max_slots; slot0 += KRES) {
+        cwct_stats_labels_pm_kernel<<<G, 512, 0, st>>>(code, L, mask_rows, p, slot0, partial, (int)per);
+        VST_RETURN_IF_LAUNCH_FAILED();
+        cwct_stats_mean_kernel<<<dim3(N / 16, KRES), 256, 0, st>>>(partial, G, N, stats, KRES, slot0, &p->n_slots);
+        cwct_stats_cov_kernel<<<dim3(N * N / 16, KRES), 256, 0, st>>>(partial, G, N, stats, KRES, slot0, &p->n_slots);
+        VST_RETURN_IF_LAUNCH_FAILED();
+    }
+    return VST_OK;
+}
+
+int vst_cwct_apply_labels_code(const float* code, float* out, int H, int W, const float* affines, const uint8_t* mask_rows,
+                               const void* plan, int max_slots, void* stream) {
+    if (!code || !out || !affines || !mask_rows || !plan) return VST_E_ARG;
+    if (max_slots < 1 || max_slots > 8) return VST_E_SHAPE;               // one fragment set of 8 slots in LDS
+    return vst3_apply_labels_code(code, out, out + (size_t)H * W * 16, nullptr, H, W, affines, mask_rows, plan, max_slots, stream);
 }
 
 }  // extern "C"

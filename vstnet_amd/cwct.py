@@ -42,6 +42,7 @@ class MaskPlan:
 
     def __init__(self):
         self.cm, self.sm, self.tables, self.shapes, self.style, self.max_slots = [], [], [], None, None, 0
+        self.cm_rows = None        # the content label maps in a PackedCode's row order (made on first use)
 
 
 class cWCT(nn.Module):
@@ -112,7 +113,7 @@ class cWCT(nn.Module):
     @staticmethod
     def _is_packed(x):
         """A photorealistic code still in the coupling blocks' layout, no cWCT pending on it (code.py)."""
-        return isinstance(x, PackedCode) and x.pending_affines is None
+        return isinstance(x, PackedCode) and not x.pending
 
     def factor(self, content_stats, style_stats_list, alphas, alpha_c, N, min_tries=None):
         """{T, t0} with T = (sum_i a_i chol(Cs_i) [blended with chol(Cc)]) * chol(Cc)^-1.  min_tries: device int32
@@ -316,6 +317,8 @@ class cWCT(nn.Module):
         B, N, cH, cW = content_feat.shape
         if tuple(content_feat.shape) != plan.shapes[0]:
             raise ValueError(f"plan was made for a content code of shape {plan.shapes[0]}, got {tuple(content_feat.shape)}")
+        if self._is_packed(content_feat) and 1 <= int(plan.max_slots) <= 8:
+            return self._transfer_with_plan_packed(content_feat, style_feat, plan)
         in_dtype = content_feat.dtype
         c = self._prep(content_feat).reshape(B, N, -1)
         s = None
@@ -340,6 +343,43 @@ class cWCT(nn.Module):
                                                    _ptr(tab), ms, prec, _stream_ptr()), "vst_cwct_apply_labels")
             self.last_info = info
         return out.to(in_dtype).reshape(B, N, cH, cW)
+
+    def _transfer_with_plan_packed(self, content, style_feat, plan):
+        """transfer_with_plan on a PackedCode (photorealistic codes, at most 8 label slots, known after learn_slots): the
+        per-label statistics run on the packed rows with the label map in the rows' order (made once per plan), and the result
+        is the same rows with the per-row maps pending - the inverse pass applies them while it loads its state."""
+        B, N, cH, cW = content.shape
+        L = _lib.lib()
+        ms = int(plan.max_slots)
+        dev = content.packed.device
+        if plan.cm_rows is None:
+            plan.cm_rows = []
+            for b in range(B):
+                rows = torch.empty_like(plan.cm[b])
+                with torch.cuda.device(dev):
+                    _lib.check(L.vst_mask_to_code(_ptr(plan.cm[b]), _ptr(rows), cH, cW, _stream_ptr()), "vst_mask_to_code")
+                plan.cm_rows.append(rows)
+        s = None
+        if plan.style is None:
+            if style_feat is None or tuple(style_feat.shape) != plan.shapes[1]:
+                raise ValueError("transfer_with_plan needs the style code the plan was made for (or bind_style first)")
+            s = self._prep(style_feat).reshape(B, N, -1)
+        per_image = []
+        ws = self._workspace(L.vst_cwct_stats_labels_code_workspace_bytes(cH, cW), dev)
+        for b in range(B):
+            tab = plan.tables[b]
+            cs = torch.empty(self.MAX_SLOTS * (1 + N + N * N), dtype=torch.float64, device=dev)
+            ss = plan.style[b] if plan.style is not None else self._stats_labels(s[b], plan.sm[b], tab, ms)
+            affines = torch.empty(self.MAX_SLOTS * (N * N + N), dtype=torch.float32, device=dev)
+            info = torch.empty(self.MAX_SLOTS * 3, dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(L.vst_cwct_stats_labels_code(_ptr(content.packed[b]), cH, cW, _ptr(plan.cm_rows[b]), _ptr(tab), ms,
+                                                        _ptr(cs), _ptr(ws), _stream_ptr()), "vst_cwct_stats_labels_code")
+                _lib.check(L.vst_cwct_factor_labels(_ptr(cs), _ptr(ss), _ptr(tab), ms, float(self.eps), N, _ptr(affines),
+                                                    _ptr(info), _stream_ptr()), "vst_cwct_factor_labels")
+            self.last_info = info
+            per_image.append((affines, plan.cm_rows[b], tab))
+        return content.with_label_affines(per_image, ms)
 
     # ------------------------------------------------------------------ per-label form (N = 16 only)
     def _transfer_seg_per_label(self, content_feat, style_feat, cmask, smask):

@@ -228,7 +228,7 @@ class RevResNet(nn.Module):
 
     def _decode_packed(self, z, u8):
         """Inverse pass straight from the packed rows; a pending cWCT affine map is applied while the state is loaded."""
-        code, aff = z.packed, z.pending_affines
+        code, aff, lab = z.packed, z.pending_affines, z.pending_labels
         if not code.is_cuda:
             raise RuntimeError("vstnet_amd.RevResNet runs on ROCm devices only (no CPU fallback)")
         B = code.shape[0]
@@ -242,6 +242,19 @@ class RevResNet(nn.Module):
         ws = self._get_workspace(L.vst_pass_workspace_bytes(1, H, W), code.device)
         aptr = C.c_void_p(aff.data_ptr()) if aff is not None else C.c_void_p(0)
         with torch.cuda.device(code.device):
+            if lab is not None:                  # a masked cWCT is pending: one decode per image, a map per row
+                per_image, ms = lab
+                prec = _PRECISIONS[self.precision]
+                for b in range(B):
+                    a_b, rows_b, plan_b = per_image[b]
+                    args = (C.byref(net), C.c_void_p(code[b].data_ptr()), C.c_void_p(a_b.data_ptr()), C.c_void_p(rows_b.data_ptr()),
+                            C.c_void_p(plan_b.data_ptr()), ms, C.c_void_p(out[b].data_ptr()), C.c_void_p(ws.data_ptr()))
+                    if u8:
+                        _lib.check(L.vst_revnet_decode_labels_u8(*args, H, W, prec, _stream_ptr()), "vst_revnet_decode_labels_u8")
+                    else:
+                        _lib.check(L.vst_revnet_decode_labels(*args, self.in_channel, H, W, prec, _stream_ptr()),
+                                   "vst_revnet_decode_labels")
+                return out
             if u8:
                 _lib.check(L.vst_revnet_decode_u8(C.byref(net), C.c_void_p(code.data_ptr()), aptr, C.c_void_p(out.data_ptr()),
                                                   C.c_void_p(ws.data_ptr()), B, H, W, _PRECISIONS[self.precision],
