@@ -110,6 +110,9 @@ int vst_block_apply(const vst_block_weights* w, int channel, int stride, int dir
  * workspace: vst_pass_workspace_bytes(B,H,W).
  * ------------------------------------------------------------------------------------------- */
 size_t vst_pass_workspace_bytes(int B, int H, int W);
+/* images per internal sub-batch of vst_revnet_forward / _inverse for this shape (the passes keep a sub-batch's working set
+ * inside the 256 MiB Infinity Cache); 1 = the passes run image by image.  < 0: VST_E_SHAPE. */
+int vst_pass_sub_batch(int B, int H, int W);
 int vst_revnet_forward(const vst_net_weights* w, const float* x, float* z, void* workspace,
                        int B, int C_in, int H, int W, int sp_steps, int precision, void* stream);
 int vst_revnet_inverse(const vst_net_weights* w, const float* z, float* x, void* workspace,

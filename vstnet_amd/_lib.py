@@ -33,7 +33,7 @@ EXPORTS = [
     "vst_revnet_encode", "vst_revnet_encode_u8", "vst_revnet_decode", "vst_revnet_decode_u8", "vst_code_to_z", "vst_z_to_code",
     "vst_cwct_stats_code_workspace_bytes", "vst_cwct_stats_code", "vst_cwct_apply_code",
     "vst_mask_to_code", "vst_cwct_stats_labels_code_workspace_bytes", "vst_cwct_stats_labels_code", "vst_cwct_apply_labels_code",
-    "vst_revnet_decode_labels", "vst_revnet_decode_labels_u8",
+    "vst_revnet_decode_labels", "vst_revnet_decode_labels_u8", "vst_pass_sub_batch",
 ]
 
 
@@ -113,6 +113,7 @@ def lib() -> C.CDLL:
         "vst_block_tmp_bytes": (sz, [i, i, i]),
         "vst_block_apply": (i, [C.POINTER(BlockWeights), i, i, i, i, vp, vp, vp, i, i, i, vp]),
         "vst_pass_workspace_bytes": (sz, [i, i, i]),
+        "vst_pass_sub_batch": (i, [i, i, i]),
         "vst_revnet_forward": (i, [C.POINTER(NetWeights), vp, vp, vp, i, i, i, i, i, i, vp]),
         "vst_revnet_inverse": (i, [C.POINTER(NetWeights), vp, vp, vp, i, i, i, i, i, i, vp]),
         "vst_cwct_stats_workspace_bytes": (sz, [i, lg]),

@@ -1283,6 +1283,11 @@ static int revnet_decode_any(const vst_net_weights* w, const float* code, const 
     return VST_OK;
 }
 
+extern "C" int vst_pass_sub_batch(int B, int H, int W) {
+    if (!vst_shape_ok(B, H, W)) return VST_E_SHAPE;
+    return pass_sub_batch(B, H, W);
+}
+
 static int revnet_forward_any(const vst_net_weights* w, const float* x, const uint8_t* x_u8, float* z, void* workspace,
                               int B, int C_in, int H, int W, int sp_steps, int precision, void* stream) {
     if (!w || (!x && !x_u8) || !z) return VST_E_ARG;

@@ -220,11 +220,11 @@ class RevResNet(nn.Module):
 
     def _use_packed(self, B, H, W):
         """The packed passes run one image at a time (an image's two state halves are adjacent in the code).  That is what
-        the dense passes do anyway once an image's working set reaches the cache budget (conv.hip, pass_sub_batch: 192 MiB /
-        288 B per pixel); batches of SMALL images keep the dense route, whose launches cover several images."""
+        the dense passes do anyway once an image's working set reaches their cache budget (vst_pass_sub_batch == 1);
+        batches of SMALL images keep the dense route, whose launches cover several images."""
         if self.packed_code == "always":
             return True
-        return bool(self.packed_code) and (B == 1 or (192 << 20) // (H * W * 288) <= 1)
+        return bool(self.packed_code) and (B == 1 or _lib.lib().vst_pass_sub_batch(B, H, W) == 1)
 
     def _decode_packed(self, z, u8):
         """Inverse pass straight from the packed rows; a pending cWCT affine map is applied while the state is loaded."""
