@@ -125,36 +125,38 @@ int vst_revnet_inverse_u8(const vst_net_weights* w, const float* z, uint8_t* fra
                           int B, int H, int W, int sp_steps, int precision, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Packed code (photorealistic mode, sp_steps = 2).  The reference's forward pass ends with merge + two unsqueeze steps
- * (RevResNet.py:139-144, :219-222) that only permute (channel, pixel) pairs, and its inverse starts by undoing them
- * (:148-154, :228-231); an unmasked cWCT (cWCT.py:24-47, :206-262) is indifferent to the order of the pixels.  So the
- * code can stay in the layout the coupling blocks leave it in: `code` = float[B][2 halves][H/4][W/4][256], i.e. one
- * 32-float row per full-resolution pixel (cell (h,w) of half i holds rows of the pixels (4h+2i+i', 4w+2j+j'), in the
- * order (j, i', j')); the same number of floats as z.
- *   vst_revnet_encode[_u8] : forward pass without the spread; the state halves are written straight into `code`.
- *   vst_revnet_decode[_u8] : inverse pass without the gather.  `affines` (NULL, or float[B][32*32+32] as produced by
+ * Packed code.  The reference's forward pass ends with merge + unsqueeze steps (RevResNet.py:139-144, :219-222) that only
+ * permute (channel, pixel) pairs, and its inverse starts by undoing them (:148-154, :228-231); an unmasked cWCT
+ * (cWCT.py:24-47, :206-262) is indifferent to the order of the pixels.  So the code can stay in the layout the coupling
+ * blocks leave it in: `code` = float[B][2 halves][H/4][W/4][256] (the same number of floats as z), i.e. one row of N floats
+ * per code pixel: sp_steps = 2 (photorealistic, N = 32): cell (h,w) of half i holds the rows of the pixels
+ * (4h+2i+i', 4w+2j+j') in the order (j, i', j'); sp_steps = 1 (artistic, N = 128, z = [B,128,H/2,W/2]): the rows of the
+ * pixels (2h+i, 2w+j), j = 0, 1.
+ *   vst_revnet_encode[_u8] : forward pass without the spread; the state halves are written straight into `code`
+ *                            (the same for both modes).
+ *   vst_revnet_decode[_u8] : inverse pass without the gather.  `affines` (NULL, or float[B][N*N+N] as produced by
  *                            vst_cwct_factor): y = T x + t0 is applied to every row of image b first - the cWCT of
  *                            that frame - while the state is loaded (`code` itself is not modified).
- *   vst_code_to_z / vst_z_to_code : the permutation itself (z[B,32,H,W] <-> code), for callers that want to look at z.
- *   vst_cwct_stats_code    : vst_cwct_stats (N = 32, L = H*W, no mask) of ONE image's code; same stats record.
+ *   vst_code_to_z / vst_z_to_code : the permutation itself (z <-> code), for callers that want to look at z.
+ *   vst_cwct_stats_code    : vst_cwct_stats (all pixels, no mask) of ONE image's code; same stats record.
  *   vst_cwct_apply_code    : y = T x + t0 on one image's code, out of place or in place (out may alias code).
  * workspace: vst_pass_workspace_bytes(1,H,W) for the passes (images are processed one at a time),
- * vst_cwct_stats_code_workspace_bytes(H,W) for the statistics.
+ * vst_cwct_stats_code_workspace_bytes(H,W,sp_steps) for the statistics.
  * ------------------------------------------------------------------------------------------- */
 int vst_revnet_encode(const vst_net_weights* w, const float* x, float* code, void* workspace,
                       int B, int C_in, int H, int W, int precision, void* stream);
 int vst_revnet_encode_u8(const vst_net_weights* w, const uint8_t* frames_hwc, float* code, void* workspace,
                          int B, int H, int W, int precision, void* stream);
 int vst_revnet_decode(const vst_net_weights* w, const float* code, const float* affines, float* x, void* workspace,
-                      int B, int C_out, int H, int W, int precision, void* stream);
+                      int B, int C_out, int H, int W, int sp_steps, int precision, void* stream);
 int vst_revnet_decode_u8(const vst_net_weights* w, const float* code, const float* affines, uint8_t* frames_hwc,
-                         void* workspace, int B, int H, int W, int precision, void* stream);
-int vst_code_to_z(const float* code, float* z, int B, int H, int W, void* stream);
-int vst_z_to_code(const float* z, float* code, int B, int H, int W, void* stream);
-size_t vst_cwct_stats_code_workspace_bytes(int H, int W);
-int vst_cwct_stats_code(const float* code, int H, int W, double* stats, void* workspace, void* stream);
-int vst_cwct_apply_code(const float* code, float* out, int H, int W, const float* affine, void* stream);
-/* Masked transfer (cWCT.py:49-109) on ONE image's packed code.  `mask_rows` = the label of every row, i.e. the [H][W] label
+                         void* workspace, int B, int H, int W, int sp_steps, int precision, void* stream);
+int vst_code_to_z(const float* code, float* z, int B, int H, int W, int sp_steps, void* stream);
+int vst_z_to_code(const float* z, float* code, int B, int H, int W, int sp_steps, void* stream);
+size_t vst_cwct_stats_code_workspace_bytes(int H, int W, int sp_steps);
+int vst_cwct_stats_code(const float* code, int H, int W, int sp_steps, double* stats, void* workspace, void* stream);
+int vst_cwct_apply_code(const float* code, float* out, int H, int W, int sp_steps, const float* affine, void* stream);
+/* Masked transfer (cWCT.py:49-109) on ONE image's packed code (photorealistic codes, sp_steps = 2, only).  `mask_rows` = the label of every row, i.e. the [H][W] label
  * map in the code's pixel order (vst_mask_to_code; once per mask).  plan / max_slots / affines as in the vst_cwct_*_labels
  * calls below (vst_label_plan works on the label maps in any order); the apply and the decode take at most 8 slots
  * (VST_E_SHAPE otherwise: use the z route), the statistics any number.  Rows whose label has no slot keep their values. */

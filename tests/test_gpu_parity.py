@@ -717,6 +717,7 @@ def test_art_mode_inplace_and_masked_128():
     >= 2000-pixel region, pointwise against the oracle"""
     from models.cWCT import cWCT
     net, sd, sp = make_net("art")
+    net.packed_code = False                           # the dense [B,128,H/2,W/2] route (packed codes: test_packed_code_artistic)
     cw = cWCT(resize_masks=True)
     H, W = 192, 256                                   # code 96 x 128 = 12288 pixels (L % 64 == 0: split-operand kernel)
     xc, xs = synthetic_frames(1, H, W, seed=71), synthetic_frames(1, H, W, seed=72)
@@ -962,3 +963,38 @@ def test_packed_code_masked_transfer(kind):
         out1 = cw.transfer_with_plan(z, zs, cw.learn_slots(plan))
         assert (not isinstance(out1, PackedCode)) == (plan.max_slots > 8)
         assert_close(out1 if not isinstance(out1, PackedCode) else out1.materialize(), out0, 1e-5, "11 labels", tol_max=1e-4)
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "bf16x3"])
+def test_packed_code_artistic(precision):
+    """The artistic net's code [B,128,H/2,W/2] as a PackedCode: rows of 128 floats; statistics on ten 32 x 32 MFMA blocks,
+    the affine map on the exact-fp32 MFMA inside the decode.  Against the dense route and the oracle."""
+    from models.cWCT import cWCT
+    from vstnet_amd.code import PackedCode, from_dense
+    net, sd, sp = make_net("art", precision)
+    net.packed_code = "always"
+    dense, _, _ = make_net("art", precision)
+    dense.packed_code = False
+    cw = cWCT(precision="fp32")                  # the dense N = 128 apply in exact fp32 as well
+    for B, H, W, tol in ((1, 64, 96, 1e-4), (2, 40, 24, 5e-4), (1, 256, 256, 2e-5), (1, 12, 20, 5e-4)):
+        x, xs = synthetic_frames(B, H, W, seed=5).cuda(), synthetic_frames(B, H, W, seed=6).cuda()
+        with torch.no_grad():
+            z, zd = net(x), dense(x)
+            assert isinstance(z, PackedCode) and tuple(z.shape) == tuple(zd.shape) == (B, 128, H // 2, W // 2)
+            assert torch.equal(z.materialize(), zd) and torch.equal(from_dense(zd).materialize(), zd)
+            assert torch.equal(net(z, forward=False), dense(zd, forward=False)), "plain decode"
+            zs, zsd = net(xs), dense(xs)
+            t, td = cw.transfer(z, zs), cw.transfer(zd, zsd)
+            assert isinstance(t, PackedCode) and t.pending_affines is not None
+            # two summation orders of a 128 x 128 covariance; with few pixels (L < 128: the jitter path) it is ill-conditioned
+            assert_close(t.materialize(), td, tol, f"artistic transfer on packed rows {B}x{H}x{W}")
+            assert float((net(t, forward=False) - dense(td, forward=False)).abs().max()) <= 5 * tol
+            assert_close(net(cw.transfer_with_stats(z, cw.style_stats(zs)), forward=False), dense(td, forward=False), 5 * tol,
+                         "cached style")
+            assert int((net.inverse_u8(t).int() - dense.inverse_u8(td).int()).abs().max()) <= 1
+    x, xs = synthetic_frames(1, 64, 64, seed=0), synthetic_frames(1, 64, 64, seed=1)
+    with torch.no_grad():
+        got = net(cw.transfer(net(x.cuda()), net(xs.cuda())), forward=False)
+    zc, zs_ = cpu_ref.revnet_forward(x, sd, sp), cpu_ref.revnet_forward(xs, sd, sp)
+    ref = cpu_ref.revnet_inverse(cpu_ref.transfer(zc, zs_), sd, sp)
+    assert_close(got, ref, 2e-4 if precision == "f16x2" else TIGHT, "artistic stylised frame through the packed code vs oracle")

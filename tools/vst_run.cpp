@@ -82,18 +82,18 @@ int main(int argc, char** argv) {
     const int N = sp == 2 ? 32 : 128;
     const long L = sp == 2 ? (long)H * W : (long)H * W / 4, Ls = sp == 2 ? (long)Hs * Ws : (long)Hs * Ws / 4;
     uint8_t *d_c, *d_s, *d_out;
-    float *z_c, *z_s, *z_cs, *affine;
+    float *z_c, *z_s, *affine;
     double *st_c, *st_s;
     int* info;
     void *ws, *cws;
     const size_t wbytes = vst_pass_workspace_bytes(1, H > Hs ? H : Hs, W > Ws ? W : Ws);
     HIP_OK(hipMalloc(&d_c, content.size())); HIP_OK(hipMalloc(&d_s, style.size())); HIP_OK(hipMalloc(&d_out, content.size()));
-    HIP_OK(hipMalloc(&z_c, (size_t)N * L * 4)); HIP_OK(hipMalloc(&z_cs, (size_t)N * L * 4)); HIP_OK(hipMalloc(&z_s, (size_t)N * Ls * 4));
+    HIP_OK(hipMalloc(&z_c, (size_t)N * L * 4)); HIP_OK(hipMalloc(&z_s, (size_t)N * Ls * 4));
     HIP_OK(hipMalloc(&affine, ((size_t)N * N + N) * 4));
     HIP_OK(hipMalloc(&st_c, (1 + N + (size_t)N * N) * 8)); HIP_OK(hipMalloc(&st_s, (1 + N + (size_t)N * N) * 8));
     HIP_OK(hipMalloc(&info, 16)); HIP_OK(hipMalloc(&ws, wbytes));
     size_t cwb = vst_cwct_stats_workspace_bytes(N, L), cwb2 = vst_cwct_stats_workspace_bytes(N, Ls);
-    if (vst_cwct_stats_code_workspace_bytes(H, W) > cwb) cwb = vst_cwct_stats_code_workspace_bytes(H, W);
+    if (vst_cwct_stats_code_workspace_bytes(H, W, sp) > cwb) cwb = vst_cwct_stats_code_workspace_bytes(H, W, sp);
     HIP_OK(hipMalloc(&cws, cwb > cwb2 ? cwb : cwb2));
     HIP_OK(hipMemcpyAsync(d_c, content.data(), content.size(), hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(d_s, style.data(), style.size(), hipMemcpyHostToDevice, st));
@@ -101,26 +101,15 @@ int main(int argc, char** argv) {
     // ---- the hot path ---------------------------------------------------------------------------------------------------
     const double* styles[1] = {st_s};
     const float alphas[1] = {1.f};
-    if (sp == 2) {
-        // photorealistic: the code stays in the coupling blocks' layout ("Packed code" in vstnet.h): no spread / gather, the
-        // statistics run on the packed rows and the affine map is applied while the inverse pass loads its state
-        VST_CALL(vst_revnet_encode_u8(&net, d_c, z_c, ws, 1, H, W, prec, st));
-        VST_CALL(vst_revnet_encode_u8(&net, d_s, z_s, ws, 1, Hs, Ws, prec, st));
-        VST_CALL(vst_cwct_stats_code(z_s, Hs, Ws, st_s, cws, st));
-        VST_CALL(vst_cwct_prefactor(st_s, N, 2e-5f, st_s, info, st));
-        VST_CALL(vst_cwct_stats_code(z_c, H, W, st_c, cws, st));
-        VST_CALL(vst_cwct_factor(st_c, styles, alphas, 1, 0.f, 2e-5f, N, affine, info, st));
-        VST_CALL(vst_revnet_decode_u8(&net, z_c, affine, d_out, ws, 1, H, W, prec, st));
-    } else {
-        VST_CALL(vst_revnet_forward_u8(&net, d_c, z_c, ws, 1, H, W, sp, prec, st));
-        VST_CALL(vst_revnet_forward_u8(&net, d_s, z_s, ws, 1, Hs, Ws, sp, prec, st));
-        VST_CALL(vst_cwct_stats(z_s, N, Ls, nullptr, 0, st_s, cws, st));
-        VST_CALL(vst_cwct_prefactor(st_s, N, 2e-5f, st_s, info, st));
-        VST_CALL(vst_cwct_stats(z_c, N, L, nullptr, 0, st_c, cws, st));
-        VST_CALL(vst_cwct_factor(st_c, styles, alphas, 1, 0.f, 2e-5f, N, affine, info, st));
-        VST_CALL(vst_cwct_apply_prec(z_c, z_cs, N, L, affine, nullptr, 0, prec, st));
-        VST_CALL(vst_revnet_inverse_u8(&net, z_cs, d_out, ws, 1, H, W, sp, prec, st));
-    }
+    // the code stays in the coupling blocks' layout ("Packed code" in vstnet.h): no spread / gather, the statistics run on the
+    // packed rows and the affine map is applied while the inverse pass loads its state
+    VST_CALL(vst_revnet_encode_u8(&net, d_c, z_c, ws, 1, H, W, prec, st));
+    VST_CALL(vst_revnet_encode_u8(&net, d_s, z_s, ws, 1, Hs, Ws, prec, st));
+    VST_CALL(vst_cwct_stats_code(z_s, Hs, Ws, sp, st_s, cws, st));
+    VST_CALL(vst_cwct_prefactor(st_s, N, 2e-5f, st_s, info, st));
+    VST_CALL(vst_cwct_stats_code(z_c, H, W, sp, st_c, cws, st));
+    VST_CALL(vst_cwct_factor(st_c, styles, alphas, 1, 0.f, 2e-5f, N, affine, info, st));
+    VST_CALL(vst_revnet_decode_u8(&net, z_c, affine, d_out, ws, 1, H, W, sp, prec, st));
 
     std::vector<uint8_t> out(content.size());
     HIP_OK(hipMemcpyAsync(out.data(), d_out, out.size(), hipMemcpyDeviceToHost, st));

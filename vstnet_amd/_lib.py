@@ -129,13 +129,13 @@ def lib() -> C.CDLL:
         "vst_cwct_apply_labels": (i, [vp, vp, i, lg, vp, vp, vp, i, i, vp]),
         "vst_revnet_encode": (i, [C.POINTER(NetWeights), vp, vp, vp, i, i, i, i, i, vp]),
         "vst_revnet_encode_u8": (i, [C.POINTER(NetWeights), vp, vp, vp, i, i, i, i, vp]),
-        "vst_revnet_decode": (i, [C.POINTER(NetWeights), vp, vp, vp, vp, i, i, i, i, i, vp]),
-        "vst_revnet_decode_u8": (i, [C.POINTER(NetWeights), vp, vp, vp, vp, i, i, i, i, vp]),
-        "vst_code_to_z": (i, [vp, vp, i, i, i, vp]),
-        "vst_z_to_code": (i, [vp, vp, i, i, i, vp]),
-        "vst_cwct_stats_code_workspace_bytes": (sz, [i, i]),
-        "vst_cwct_stats_code": (i, [vp, i, i, vp, vp, vp]),
-        "vst_cwct_apply_code": (i, [vp, vp, i, i, vp, vp]),
+        "vst_revnet_decode": (i, [C.POINTER(NetWeights), vp, vp, vp, vp, i, i, i, i, i, i, vp]),
+        "vst_revnet_decode_u8": (i, [C.POINTER(NetWeights), vp, vp, vp, vp, i, i, i, i, i, vp]),
+        "vst_code_to_z": (i, [vp, vp, i, i, i, i, vp]),
+        "vst_z_to_code": (i, [vp, vp, i, i, i, i, vp]),
+        "vst_cwct_stats_code_workspace_bytes": (sz, [i, i, i]),
+        "vst_cwct_stats_code": (i, [vp, i, i, i, vp, vp, vp]),
+        "vst_cwct_apply_code": (i, [vp, vp, i, i, i, vp, vp]),
         "vst_mask_to_code": (i, [vp, vp, i, i, vp]),
         "vst_cwct_stats_labels_code_workspace_bytes": (sz, [i, i]),
         "vst_cwct_stats_labels_code": (i, [vp, i, i, vp, vp, i, vp, vp, vp]),

@@ -24,16 +24,17 @@ def _stream_ptr() -> C.c_void_p:
 
 
 class PackedCode(torch.Tensor):
-    """float[B][2][H/4][W/4][256] behind the interface of a [B,32,H,W] tensor (see the module docstring)."""
+    """float[B][2][H/4][W/4][256] behind the interface of the [B,32,H,W] (or [B,128,H/2,W/2]) code tensor."""
 
     @staticmethod
-    def __new__(cls, code, H, W, affines=None, labels=None):
+    def __new__(cls, code, H, W, affines=None, labels=None, sp_steps=2):
         B = code.shape[0]
-        r = torch.Tensor._make_wrapper_subclass(cls, (B, 32, H, W), dtype=torch.float32, device=code.device,
-                                                requires_grad=False)
+        shape = (B, 32, H, W) if sp_steps == 2 else (B, 128, H // 2, W // 2)
+        r = torch.Tensor._make_wrapper_subclass(cls, shape, dtype=torch.float32, device=code.device, requires_grad=False)
         r._code = code            # flat float32 [B, 32*H*W], packed rows
-        r._hw = (H, W)
-        r._affines = affines      # None, or float32 [B, 32*32+32]: y = T x + t0 still to be applied to every row of image b
+        r._hw = (H, W)            # of the IMAGE (the code of an artistic net is [B,128,H/2,W/2])
+        r._sp = sp_steps          # 2: rows of 32 (photorealistic), 1: rows of 128 (artistic)
+        r._affines = affines      # None, or float32 [B, N*N+N]: y = T x + t0 still to be applied to every row of image b
         # None, or the pending MASKED cWCT: per image (affines of its label slots [slots, 1056], labels of its rows uint8
         # [H*W], its label plan), and the slot count the launches cover
         r._labels = labels
@@ -43,11 +44,19 @@ class PackedCode(torch.Tensor):
     def __repr__(self):
         H, W = self._hw
         what = "affine" if self._affines is not None else ("masked" if self._labels is not None else "none")
-        return f"PackedCode(B={self._code.shape[0]}, H={H}, W={W}, pending={what})"
+        return f"PackedCode(B={self._code.shape[0]}, N={self.shape[1]}, image {H}x{W}, pending={what})"
 
     @property
     def packed(self):
         return self._code
+
+    @property
+    def image_hw(self):
+        return self._hw
+
+    @property
+    def sp_steps(self):
+        return self._sp
 
     @property
     def pending_affines(self):
@@ -69,12 +78,13 @@ class PackedCode(torch.Tensor):
         """The same packed rows with the affine map of a cWCT attached (composition is not supported: materialise first)."""
         assert not self.pending
         H, W = self._hw
-        return PackedCode(self._code, H, W, affines)
+        return PackedCode(self._code, H, W, affines, None, self._sp)
 
     def with_label_affines(self, per_image, max_slots):
         """The same rows with a masked cWCT attached: per_image[b] = (affines [slots,1056], row labels, label plan)."""
         assert not self.pending
         H, W = self._hw
+        assert self._sp == 2
         return PackedCode(self._code, H, W, None, (list(per_image), int(max_slots)))
 
     def applied(self):
@@ -89,7 +99,8 @@ class PackedCode(torch.Tensor):
             for b in range(self._code.shape[0]):
                 if self._affines is not None:
                     _lib.check(L.vst_cwct_apply_code(C.c_void_p(self._code[b].data_ptr()), C.c_void_p(out[b].data_ptr()), H, W,
-                                                     C.c_void_p(self._affines[b].data_ptr()), _stream_ptr()), "vst_cwct_apply_code")
+                                                     self._sp, C.c_void_p(self._affines[b].data_ptr()), _stream_ptr()),
+                               "vst_cwct_apply_code")
                 else:
                     aff, rows, plan = self._labels[0][b]
                     _lib.check(L.vst_cwct_apply_labels_code(C.c_void_p(self._code[b].data_ptr()), C.c_void_p(out[b].data_ptr()),
@@ -105,10 +116,10 @@ class PackedCode(torch.Tensor):
             L = _lib.lib()
             H, W = self._hw
             rows = self.applied()
-            z = torch.empty((rows.shape[0], 32, H, W), dtype=torch.float32, device=rows.device)
+            z = torch.empty(tuple(self.shape), dtype=torch.float32, device=rows.device)
             with torch.cuda.device(rows.device):
                 _lib.check(L.vst_code_to_z(C.c_void_p(rows.data_ptr()), C.c_void_p(z.data_ptr()), rows.shape[0], H, W,
-                                           _stream_ptr()), "vst_code_to_z")
+                                           self._sp, _stream_ptr()), "vst_code_to_z")
             self._dense = z
         return self._dense
 
@@ -120,11 +131,14 @@ class PackedCode(torch.Tensor):
 
 
 def from_dense(z):
-    """Pack a plain [B,32,H,W] code (vst_z_to_code)."""
+    """Pack a plain [B,32,H,W] or [B,128,H/2,W/2] code (vst_z_to_code)."""
     L = _lib.lib()
     z = z.detach().to(torch.float32).contiguous()
-    B, _, H, W = z.shape
+    B, N = z.shape[:2]
+    sp = 2 if N == 32 else 1
+    H, W = (z.shape[2], z.shape[3]) if sp == 2 else (2 * z.shape[2], 2 * z.shape[3])
     code = torch.empty((B, 32 * H * W), dtype=torch.float32, device=z.device)
     with torch.cuda.device(z.device):
-        _lib.check(L.vst_z_to_code(C.c_void_p(z.data_ptr()), C.c_void_p(code.data_ptr()), B, H, W, _stream_ptr()), "vst_z_to_code")
-    return PackedCode(code, H, W)
+        _lib.check(L.vst_z_to_code(C.c_void_p(z.data_ptr()), C.c_void_p(code.data_ptr()), B, H, W, sp, _stream_ptr()),
+                   "vst_z_to_code")
+    return PackedCode(code, H, W, None, None, sp)

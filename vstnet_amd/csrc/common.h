@@ -139,8 +139,8 @@ extern "C" int vst3_gather_planes(const float* z, unsigned char* s1_planes, floa
 
 int vst3_presplit(const float* state, unsigned char* planes, int B, int H, int W, void* stream);
 // cwct.hip: y = T x + t0 on the rows of one image's packed code; half 0 to out0 or (planes0 != nullptr) to split planes
-int vst3_apply_code(const float* code, float* out0, float* out1, unsigned char* planes0, int H, int W, const float* affine,
-                    void* stream);
+int vst3_apply_code(const float* code, float* out0, float* out1, unsigned char* planes0, int H, int W, int sp_steps,
+                    const float* affine, void* stream);
 
 int vst3_apply_labels_code(const float* code, float* out0, float* out1, unsigned char* planes0, int H, int W,
                            const float* affines, const uint8_t* mask_rows, const void* plan, int max_slots, void* stream);

@@ -1255,10 +1255,12 @@ static int revnet_decode_labels_any(const vst_net_weights* w, const float* code,
 }
 
 static int revnet_decode_any(const vst_net_weights* w, const float* code, const float* affines, float* x, uint8_t* x_u8,
-                             void* workspace, int B, int C_out, int H, int W, int precision, void* stream) {
+                             void* workspace, int B, int C_out, int H, int W, int sp_steps, int precision, void* stream) {
     if (!w || (!x && !x_u8) || !code) return VST_E_ARG;
     if (!workspace) return VST_E_WORKSPACE;
     if (!vst_shape_ok(B, H, W) || C_out < 1 || C_out > 16) return VST_E_SHAPE;
+    if (sp_steps != 1 && sp_steps != 2) return VST_E_MODE;
+    const int N = sp_steps == 2 ? 32 : 128;
     const size_t img = (size_t)32 * H * W;
     float* s[2] = {(float*)workspace, (float*)workspace + img / 2};
     float* tmp = (float*)workspace + img;
@@ -1269,7 +1271,7 @@ static int revnet_decode_any(const vst_net_weights* w, const float* code, const 
         const float* c = code + b * img;
         int rc;
         if (affines) {
-            rc = vst3_apply_code(c, s[0], s[1], planes0, H, W, affines + (size_t)b * (32 * 32 + 32), stream);
+            rc = vst3_apply_code(c, s[0], s[1], planes0, H, W, sp_steps, affines + (size_t)b * ((size_t)N * N + N), stream);
         } else {                                             // plain copy into the pass's state (it is updated in place)
             rc = sp ? vst3_presplit(c, planes0, 1, H, W, stream)
                     : (int)hipMemcpyAsync(s[0], c, img / 2 * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -1361,15 +1363,15 @@ int vst_revnet_encode_u8(const vst_net_weights* w, const uint8_t* frames_hwc, fl
 }
 
 int vst_revnet_decode(const vst_net_weights* w, const float* code, const float* affines, float* x, void* workspace, int B,
-                      int C_out, int H, int W, int precision, void* stream) {
+                      int C_out, int H, int W, int sp_steps, int precision, void* stream) {
     if (!x) return VST_E_ARG;
-    return revnet_decode_any(w, code, affines, x, nullptr, workspace, B, C_out, H, W, precision, stream);
+    return revnet_decode_any(w, code, affines, x, nullptr, workspace, B, C_out, H, W, sp_steps, precision, stream);
 }
 
 int vst_revnet_decode_u8(const vst_net_weights* w, const float* code, const float* affines, uint8_t* frames_hwc, void* workspace,
-                         int B, int H, int W, int precision, void* stream) {
+                         int B, int H, int W, int sp_steps, int precision, void* stream) {
     if (!frames_hwc) return VST_E_ARG;
-    return revnet_decode_any(w, code, affines, nullptr, frames_hwc, workspace, B, 3, H, W, precision, stream);
+    return revnet_decode_any(w, code, affines, nullptr, frames_hwc, workspace, B, 3, H, W, sp_steps, precision, stream);
 }
 
 int vst_revnet_decode_labels(const vst_net_weights* w, const float* code, const float* affines, const uint8_t* mask_rows,
@@ -1388,21 +1390,21 @@ int vst_revnet_decode_labels_u8(const vst_net_weights* w, const float* code, con
                                     precision, stream);
 }
 
-int vst_code_to_z(const float* code, float* z, int B, int H, int W, void* stream) {
+int vst_code_to_z(const float* code, float* z, int B, int H, int W, int sp_steps, void* stream) {
     if (!code || !z) return VST_E_ARG;
     const size_t img = (size_t)32 * H * W;
     for (int b = 0; b < B; ++b) {
-        const int rc = vst_spread(code + b * img, code + b * img + img / 2, z + b * img, 1, H, W, 2, stream);
+        const int rc = vst_spread(code + b * img, code + b * img + img / 2, z + b * img, 1, H, W, sp_steps, stream);
         if (rc) return rc;
     }
     return VST_OK;
 }
 
-int vst_z_to_code(const float* z, float* code, int B, int H, int W, void* stream) {
+int vst_z_to_code(const float* z, float* code, int B, int H, int W, int sp_steps, void* stream) {
     if (!code || !z) return VST_E_ARG;
     const size_t img = (size_t)32 * H * W;
     for (int b = 0; b < B; ++b) {
-        const int rc = vst_gather(z + b * img, code + b * img, code + b * img + img / 2, 1, H, W, 2, stream);
+        const int rc = vst_gather(z + b * img, code + b * img, code + b * img + img / 2, 1, H, W, sp_steps, stream);
         if (rc) return rc;
     }
     return VST_OK;

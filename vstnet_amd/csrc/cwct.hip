@@ -1542,6 +1542,199 @@ __global__ __launch_bounds__(256) void cwct_apply_pm_kernel(const float* __restr
     }
 }
 
+// ---- artistic codes (N = 128, z = [B,128,H/2,W/2]): rows of 128 floats, 2 per quarter-resolution cell and half ----------------
+// Statistics: the 128 x 128 co-moment as its 10 upper-triangular 32 x 32 blocks.  Lane (i, h) loads, per row pair, its float of
+// each of the four 32-channel blocks (operands a_0..a_3); block (bi, bj) += a_bi a_bj^T on v_mfma_f32_32x32x2_f32.  8 waves per
+// workgroup, two register sets of UNR row pairs in flight; the lower triangle is written as the mirror image.
+__global__ __launch_bounds__(512) void cwct_stats_pm128_kernel(const float* __restrict__ x, long L, float* __restrict__ partial,
+                                                               int px_per_wg) {
+    constexpr int N = 128, NB = 4, NACC = 10, UNR = 4, NWV = 8;
+    __shared__ float red[NWV / 2][16][64];
+    __shared__ float reds[NWV][NB][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ch = lane & 31, h = lane >> 5;
+    const long p_begin = (long)blockIdx.x * px_per_wg;
+    long p_end = p_begin + px_per_wg;
+    if (p_end > L) p_end = L;
+    float shift[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) shift[b] = p_begin < L ? x[(size_t)p_begin * N + 32 * b + ch] : 0.f;
+    const long per_wave = px_per_wg / NWV;
+    long wb = p_begin + wave * per_wave, we = wb + per_wave;
+    if (we > p_end) we = p_end;
+    f32x16 acc[NACC];
+    float asum[NB];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) asum[b] = 0.f;
+#define PM128_LOAD(dst, base)                                                                         \
+    _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                                 \
+        const long row = (base) + 2 * u + h;                                                          \
+        const float* p = x + (size_t)(row < we ? row : we - 1) * N + ch;                              \
+        _Pragma("unroll") for (int b = 0; b < NB; ++b) dst[u][b] = p[32 * b];                         \
+    }
+#define PM128_USE(src, base)                                                                          \
+    _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                                 \
+        const bool in = (base) + 2 * u + h < we;                                                      \
+        float d[NB];                                                                                  \
+        _Pragma("unroll") for (int b = 0; b < NB; ++b) {                                              \
+            d[b] = in ? src[u][b] - shift[b] : 0.f;                                                   \
+            asum[b] += d[b];                                                                          \
+        }                                                                                             \
+        int a_ = 0;                                                                                   \
+        _Pragma("unroll") for (int bi = 0; bi < NB; ++bi)                                             \
+            _Pragma("unroll") for (int bj = bi; bj < NB; ++bj, ++a_)                                  \
+                acc[a_] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[bi], d[bj], acc[a_], 0, 0, 0);       \
+    }
+    if (wb < we) {
+        float va[UNR][NB], vb[UNR][NB];
+        PM128_LOAD(va, wb)
+        for (long r0 = wb; r0 < we; r0 += 4 * UNR) {
+            PM128_LOAD(vb, r0 + 2 * UNR)
+            __builtin_amdgcn_sched_barrier(0);
+            PM128_USE(va, r0)
+            __builtin_amdgcn_sched_barrier(0);
+            PM128_LOAD(va, r0 + 4 * UNR)
+            __builtin_amdgcn_sched_barrier(0);
+            PM128_USE(vb, r0 + 2 * UNR)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef PM128_LOAD
+#undef PM128_USE
+    float* rec = partial + (size_t)blockIdx.x * cwct_partial_stride(N);
+    // row sums: one LDS round (fixed order), then the blocks one at a time through a fixed-order tree over the waves
+#pragma unroll
+    for (int b = 0; b < NB; ++b) reds[wave][b][lane] = asum[b] + __shfl_xor(asum[b], 32, 64);
+    __syncthreads();
+    if (wave == 0 && h == 0) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            float t = 0.f;
+            for (int w = 0; w < NWV; ++w) t += reds[w][b][lane];
+            rec[4 + N + 32 * b + ch] = t;
+            rec[4 + 32 * b + ch] = shift[b];
+        }
+    }
+    if (tid == 0) rec[0] = p_end > p_begin ? (float)(p_end - p_begin) : 0.f;
+    int a_ = 0;
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+        for (int bj = bi; bj < NB; ++bj, ++a_) {
+#pragma unroll
+            for (int half = NWV / 2; half >= 1; half >>= 1) {
+                __syncthreads();
+                if (wave >= half && wave < 2 * half) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[wave - half][r][lane] = acc[a_][r];
+                }
+                __syncthreads();
+                if (wave < half) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a_][r] += red[wave][r][lane];
+                }
+            }
+            if (wave == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * h, j = 32 * bj + ch;
+                    rec[4 + 2 * N + (size_t)i * N + j] = acc[a_][r];
+                    if (bi != bj) rec[4 + 2 * N + (size_t)j * N + i] = acc[a_][r];
+                }
+            }
+        }
+}
+
+// y = T x + t0 on rows of 128: D[out block ob][row] on 64 v_mfma_f32_32x32x2_f32 per 32-channel out block and 32 rows (exact
+// fp32); lane (row n, h) holds every other 16-byte piece of its row, T's fragments (64 KB, same channel order) sit in LDS.  Outputs as in cwct_apply_pm_kernel; a row is one of the
+// two 128-channel groups of its cell, so its out block ob is 32-channel group g = 4 (row & 1) + ob of the split-plane layout.
+__global__ __launch_bounds__(256) void cwct_apply_pm128_kernel(const float* __restrict__ x, float* __restrict__ out0,
+                                                               float* __restrict__ out1, unsigned char* __restrict__ planes0,
+                                                               int Hq, int Wq, const float* __restrict__ affine, long tiles) {
+    constexpr int N = 128, NB = 4, KT = 64;
+    extern __shared__ __attribute__((aligned(16))) float tl128[];        // [NB][KT][64]
+    __shared__ __attribute__((aligned(16))) float t0s[N];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    for (int idx = tid; idx < N * N; idx += 256) {          // coalesced read of T, scattered into fragment order
+        const int i = idx >> 7, c = idx & 127;
+        const int ob = i >> 5, hh = (c >> 2) & 1, t = 4 * (c >> 3) + (c & 3);
+        tl128[(ob * KT + t) * 64 + (i & 31) + 32 * hh] = affine[idx];
+    }
+    if (tid < N) t0s[tid] = affine[N * N + tid];
+    __syncthreads();
+    const long rows_half = (long)Hq * Wq * 2;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < tiles; tile += (long)gridDim.x * 4) {
+        const long row = tile * 32 + n;
+        const bool valid = row < 2 * rows_half;
+        // k-step t = 4 i + e of lane half h is channel 8 i + 4 h + e: the two halves read ADJACENT 16-byte pieces, so a 128-byte
+        // line of the row is consumed by four consecutive load instructions (with 64 h + t the eight pieces of a line were 16
+        // instructions apart and fell out of the 32 KB L1 in between: 142 us instead of 70)
+        const float4* src = (const float4*)(x + (size_t)(valid ? row : 2 * rows_half - 1) * N) + h;
+        float bv[KT];
+#pragma unroll
+        for (int i = 0; i < KT / 4; ++i) {
+            const float4 v = src[2 * i];
+            bv[4 * i] = v.x; bv[4 * i + 1] = v.y; bv[4 * i + 2] = v.z; bv[4 * i + 3] = v.w;
+        }
+        const bool half1 = row >= rows_half;
+        const long rr = half1 ? row - rows_half : row;
+        const long cell = rr >> 1;
+        const int sub = (int)(rr & 1), y = (int)(cell / Wq), xx = (int)(cell - (long)y * Wq);
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            // T's fragments 16 k-steps at a time, the next 16 fetched from LDS during the current MFMAs (left to itself the
+            // compiler waits for each ds_read in front of its MFMA: 133 us instead of 70 for a 512 x 512 code)
+            float af[2][16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) af[0][t] = tl128[(ob * KT + t) * 64 + lane];
+#pragma unroll
+            for (int tb = 0; tb < KT / 16; ++tb) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (tb + 1 < KT / 16) {
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) af[(tb + 1) & 1][t] = tl128[(ob * KT + 16 * (tb + 1) + t) * 64 + lane];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tb & 1][t], bv[16 * tb + t], acc, 0, 0, 0);
+            }
+            float o[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 tq = *(const float4*)&t0s[32 * ob + 8 * q + 4 * h];
+                o[q][0] = acc[4 * q + 0] + tq.x; o[q][1] = acc[4 * q + 1] + tq.y;
+                o[q][2] = acc[4 * q + 2] + tq.z; o[q][3] = acc[4 * q + 3] + tq.w;
+            }
+            if (!valid) continue;
+            if (!half1 && planes0 != nullptr) {
+                const int g = 4 * sub + ob;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const float f8[8] = {o[pr][0], o[pr][1], o[pr][2], o[pr][3], o[pr + 2][0], o[pr + 2][1], o[pr + 2][2], o[pr + 2][3]};
+                    u32x4 hi, lo;
+                    split8_sp(f8, hi, lo);
+                    const int cig = (g >> 1) * 8 + (g & 1) * 4 + 2 * pr + h;
+                    *(u32x4*)(planes0 + sp_offset(cig, 0, y, xx, Hq, Wq)) = hi;
+                    *(u32x4*)(planes0 + sp_offset(cig, 1, y, xx, Hq, Wq)) = lo;
+                }
+            } else {
+                float* dst = (half1 ? out1 : out0) + (size_t)rr * N + 32 * ob;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *(float4*)(dst + 8 * q + 4 * h) = make_float4(o[q][0], o[q][1], o[q][2], o[q][3]);
+            }
+        }
+    }
+}
+
 // ---- masked forms on the packed rows -------------------------------------------------------------------------------------
 // The label of row r of an image's code: rows are (half i, cell (h, w), group g = 4j + 2i' + j') <-> pixel (4h + 2i + i', 4w + 2j + j')
 __global__ __launch_bounds__(256) void mask_to_code_kernel(const uint8_t* __restrict__ mask, uint8_t* __restrict__ out, int H, int W) {
@@ -1783,15 +1976,26 @@ int vst3_apply_labels_code(const float* code, float* out0, float* out1, unsigned
 }
 
 // internal (conv.hip's decode): out0 / out1 = where the transformed halves go, planes0 (nullable) = half 0 as split planes instead
-int vst3_apply_code(const float* code, float* out0, float* out1, unsigned char* planes0, int H, int W, const float* affine,
-                    void* stream) {
+int vst3_apply_code(const float* code, float* out0, float* out1, unsigned char* planes0, int H, int W, int sp_steps,
+                    const float* affine, void* stream) {
     if (H < 8 || W < 8 || (H & 3) || (W & 3)) return VST_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    const long tiles = ((long)H * W + 31) / 32;             // 32-row tiles over the image's H * W rows
-    long wgs = (tiles + 3) / 4;
-    if (wgs > 8192) wgs = 8192;
     vst_prof_scope prof(VST_KERNEL_CWCT_APPLY, st);
-    cwct_apply_pm_kernel<<<dim3((unsigned)wgs), 256, 0, st>>>(code, out0, out1, planes0, H >> 2, W >> 2, affine, tiles);
+    if (sp_steps == 2) {
+        const long tiles = ((long)H * W + 31) / 32;         // 32-row tiles over the image's H * W rows
+        long wgs = (tiles + 3) / 4;
+        if (wgs > 8192) wgs = 8192;
+        cwct_apply_pm_kernel<<<dim3((unsigned)wgs), 256, 0, st>>>(code, out0, out1, planes0, H >> 2, W >> 2, affine, tiles);
+    } else if (sp_steps == 1) {
+        const long tiles = ((long)H * W / 4 + 31) / 32;     // H * W / 4 rows of 128
+        long wgs = (tiles + 3) / 4;
+        if (wgs > 512) wgs = 512;                            // two per CU (64 KB of fragments each, staged once)
+        static std::atomic<unsigned> attr_done{0};
+        if (int rc = vst_ensure_dynamic_lds((const void*)cwct_apply_pm128_kernel, 65536, &attr_done)) return rc;
+        cwct_apply_pm128_kernel<<<dim3((unsigned)wgs), 256, 65536, st>>>(code, out0, out1, planes0, H >> 2, W >> 2, affine, tiles);
+    } else {
+        return VST_E_MODE;
+    }
     VST_RETURN_IF_LAUNCH_FAILED();
     return VST_OK;
 }
@@ -1993,24 +2197,33 @@ int vst_cwct_apply_labels(const float* x, float* y, int N, long L, const float* 
     }
 }
 
-size_t vst_cwct_stats_code_workspace_bytes(int H, int W) {
+size_t vst_cwct_stats_code_workspace_bytes(int H, int W, int sp_steps) {
     (void)H; (void)W;
-    return (size_t)256 * cwct_partial_stride(32) * sizeof(float);      // at most 256 workgroup records
+    const int N = sp_steps == 1 ? 128 : 32;
+    return (size_t)256 * cwct_partial_stride(N) * sizeof(float);      // at most 256 workgroup records
 }
 
-int vst_cwct_stats_code(const float* code, int H, int W, double* stats, void* workspace, void* stream) {
+int vst_cwct_stats_code(const float* code, int H, int W, int sp_steps, double* stats, void* workspace, void* stream) {
     if (!code || !stats) return VST_E_ARG;
     if (!workspace) return VST_E_WORKSPACE;
     if (H < 8 || W < 8 || (H & 3) || (W & 3)) return VST_E_SHAPE;
+    if (sp_steps != 1 && sp_steps != 2) return VST_E_MODE;
     hipStream_t st = (hipStream_t)stream;
-    const long L = (long)H * W;
-    const int N = 32;
-    long per = ((L + 255) / 256 + 255) / 256 * 256;         // <= 256 workgroups of 16 waves, rows per workgroup a multiple of 256
-    const int G = (int)((L + per - 1) / per);
+    const int N = sp_steps == 1 ? 128 : 32;
+    const long L = sp_steps == 1 ? (long)H * W / 4 : (long)H * W;
     float* partial = (float*)workspace;                      // G <= 256 records: inside vst_cwct_stats_code_workspace_bytes
+    int G;
     {
         vst_prof_scope prof(VST_KERNEL_CWCT_STATS, st);
-        cwct_stats_pm_kernel<<<G, 1024, 0, st>>>(code, L, partial, (int)per);
+        if (N == 32) {
+            long per = ((L + 255) / 256 + 255) / 256 * 256;  // <= 256 workgroups of 16 waves, rows per workgroup a multiple of 256
+            G = (int)((L + per - 1) / per);
+            cwct_stats_pm_kernel<<<G, 1024, 0, st>>>(code, L, partial, (int)per);
+        } else {
+            long per = ((L + 255) / 256 + 127) / 128 * 128;  // <= 256 workgroups of 8 waves, 16-row multiples per wave
+            G = (int)((L + per - 1) / per);
+            cwct_stats_pm128_kernel<<<G, 512, 0, st>>>(code, L, partial, (int)per);
+        }
         VST_RETURN_IF_LAUNCH_FAILED();
     }
     vst_prof_scope prof(VST_KERNEL_CWCT_FACTOR, st);
@@ -2019,9 +2232,9 @@ int vst_cwct_stats_code(const float* code, int H, int W, double* stats, void* wo
     return VST_OK;
 }
 
-int vst_cwct_apply_code(const float* code, float* out, int H, int W, const float* affine, void* stream) {
+int vst_cwct_apply_code(const float* code, float* out, int H, int W, int sp_steps, const float* affine, void* stream) {
     if (!code || !out || !affine) return VST_E_ARG;
-    return vst3_apply_code(code, out, out + (size_t)H * W * 16, nullptr, H, W, affine, stream);
+    return vst3_apply_code(code, out, out + (size_t)H * W * 16, nullptr, H, W, sp_steps, affine, stream);
 }
 
 int vst_mask_to_code(const uint8_t* mask, uint8_t* mask_rows, int H, int W, void* stream) {

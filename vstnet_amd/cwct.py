@@ -100,14 +100,16 @@ class cWCT(nn.Module):
         return out
 
     def stats_code(self, z, b):
-        """stats() of image b of a PackedCode (N = 32, all pixels), on the packed rows (vst_cwct_stats_code)."""
+        """stats() of image b of a PackedCode (all pixels), on the packed rows (vst_cwct_stats_code)."""
         rows = z.applied()[b]
-        H, W = z.shape[2], z.shape[3]
+        H, W = z.image_hw
+        N = z.shape[1]
         L = _lib.lib()
-        out = torch.empty(1 + 32 + 32 * 32, dtype=torch.float64, device=rows.device)
-        ws = self._workspace(L.vst_cwct_stats_code_workspace_bytes(H, W), rows.device)
+        out = torch.empty(1 + N + N * N, dtype=torch.float64, device=rows.device)
+        ws = self._workspace(L.vst_cwct_stats_code_workspace_bytes(H, W, z.sp_steps), rows.device)
         with torch.cuda.device(rows.device):
-            _lib.check(L.vst_cwct_stats_code(_ptr(rows), H, W, _ptr(out), _ptr(ws), _stream_ptr()), "vst_cwct_stats_code")
+            _lib.check(L.vst_cwct_stats_code(_ptr(rows), H, W, z.sp_steps, _ptr(out), _ptr(ws), _stream_ptr()),
+                       "vst_cwct_stats_code")
         return out
 
     @staticmethod
@@ -317,7 +319,7 @@ class cWCT(nn.Module):
         B, N, cH, cW = content_feat.shape
         if tuple(content_feat.shape) != plan.shapes[0]:
             raise ValueError(f"plan was made for a content code of shape {plan.shapes[0]}, got {tuple(content_feat.shape)}")
-        if self._is_packed(content_feat) and 1 <= int(plan.max_slots) <= 8:
+        if self._is_packed(content_feat) and content_feat.sp_steps == 2 and 1 <= int(plan.max_slots) <= 8:
             return self._transfer_with_plan_packed(content_feat, style_feat, plan)
         in_dtype = content_feat.dtype
         c = self._prep(content_feat).reshape(B, N, -1)

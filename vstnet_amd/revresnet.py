@@ -182,14 +182,14 @@ class RevResNet(nn.Module):
         L = _lib.lib()
         net = self._ensure_packed(x.device)
         s = self.sp_steps
-        if s == 2 and self._use_packed(B, H, W):  # photorealistic mode: the code stays in the blocks' layout (code.py)
+        if self._use_packed(B, H, W):            # the code stays in the coupling blocks' layout (code.py)
             code = torch.empty((B, 32 * H * W), dtype=torch.float32, device=x.device)
             ws = self._get_workspace(L.vst_pass_workspace_bytes(1, H, W), x.device)
             with torch.cuda.device(x.device):
                 _lib.check(L.vst_revnet_encode(C.byref(net), C.c_void_p(x.data_ptr()), C.c_void_p(code.data_ptr()),
                                                C.c_void_p(ws.data_ptr()), B, self.in_channel, H, W,
                                                _PRECISIONS[self.precision], _stream_ptr()), "vst_revnet_encode")
-            return PackedCode(code, H, W)
+            return PackedCode(code, H, W, None, None, s)
         z = torch.empty((B, 32, H, W) if s == 2 else (B, 128, H // 2, W // 2), dtype=torch.float32, device=x.device)
         ws = self._get_workspace(L.vst_pass_workspace_bytes(B, H, W), x.device)
         with torch.cuda.device(x.device):
@@ -201,7 +201,7 @@ class RevResNet(nn.Module):
     def _inverse(self, z):
         """models/RevResNet.py:225-239."""
         s = self.sp_steps
-        if isinstance(z, PackedCode) and s == 2:
+        if isinstance(z, PackedCode) and z.sp_steps == s:
             return self._decode_packed(z, u8=False)
         z = self._check(z, 32 if s == 2 else 128, "RevResNet inverse input")
         B = z.shape[0]
@@ -232,7 +232,7 @@ class RevResNet(nn.Module):
         if not code.is_cuda:
             raise RuntimeError("vstnet_amd.RevResNet runs on ROCm devices only (no CPU fallback)")
         B = code.shape[0]
-        H, W = z.shape[2], z.shape[3]
+        H, W = z.image_hw
         L = _lib.lib()
         net = self._ensure_packed(code.device)
         out = torch.empty((B, H, W, 3) if u8 else (B, self.in_channel, H, W), dtype=torch.uint8 if u8 else torch.float32,
@@ -257,11 +257,11 @@ class RevResNet(nn.Module):
                 return out
             if u8:
                 _lib.check(L.vst_revnet_decode_u8(C.byref(net), C.c_void_p(code.data_ptr()), aptr, C.c_void_p(out.data_ptr()),
-                                                  C.c_void_p(ws.data_ptr()), B, H, W, _PRECISIONS[self.precision],
-                                                  _stream_ptr()), "vst_revnet_decode_u8")
+                                                  C.c_void_p(ws.data_ptr()), B, H, W, self.sp_steps,
+                                                  _PRECISIONS[self.precision], _stream_ptr()), "vst_revnet_decode_u8")
             else:
                 _lib.check(L.vst_revnet_decode(C.byref(net), C.c_void_p(code.data_ptr()), aptr, C.c_void_p(out.data_ptr()),
-                                               C.c_void_p(ws.data_ptr()), B, self.in_channel, H, W,
+                                               C.c_void_p(ws.data_ptr()), B, self.in_channel, H, W, self.sp_steps,
                                                _PRECISIONS[self.precision], _stream_ptr()), "vst_revnet_decode")
         return out
 
@@ -280,14 +280,14 @@ class RevResNet(nn.Module):
         L = _lib.lib()
         net = self._ensure_packed(frames.device)
         s = self.sp_steps
-        if s == 2 and self._use_packed(B, H, W):
+        if self._use_packed(B, H, W):
             code = torch.empty((B, 32 * H * W), dtype=torch.float32, device=frames.device)
             ws = self._get_workspace(L.vst_pass_workspace_bytes(1, H, W), frames.device)
             with torch.cuda.device(frames.device):
                 _lib.check(L.vst_revnet_encode_u8(C.byref(net), C.c_void_p(frames.data_ptr()), C.c_void_p(code.data_ptr()),
                                                   C.c_void_p(ws.data_ptr()), B, H, W, _PRECISIONS[self.precision],
                                                   _stream_ptr()), "vst_revnet_encode_u8")
-            return PackedCode(code, H, W)
+            return PackedCode(code, H, W, None, None, s)
         z = torch.empty((B, 32, H, W) if s == 2 else (B, 128, H // 2, W // 2), dtype=torch.float32, device=frames.device)
         ws = self._get_workspace(L.vst_pass_workspace_bytes(B, H, W), frames.device)
         with torch.cuda.device(frames.device):
@@ -300,7 +300,7 @@ class RevResNet(nn.Module):
         """Decode a code to uint8 HWC frames with the reference's quantisation: mul(255).clamp(0,255).byte()
         (truncation; image_transfer.py:217-218, video_transfer.py:212) fused into the last boundary kernel."""
         s = self.sp_steps
-        if isinstance(z, PackedCode) and s == 2:
+        if isinstance(z, PackedCode) and z.sp_steps == s:
             return self._decode_packed(z, u8=True)
         z = self._check(z, 32 if s == 2 else 128, "RevResNet inverse input")
         B = z.shape[0]
