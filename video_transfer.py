@@ -119,7 +119,8 @@ def main(argv=None):
         if masked:      # one label map for every frame and one style: histograms, uploads and the style side happen once
             with torch.no_grad():
                 zc_shape = (1, 32, ch_, cw_) if net.sp_steps == 2 else (1, 128, ch_ // 2, cw_ // 2)
-                plan = cwct.bind_style(cwct.plan_masks(content_seg, style_seg, zc_shape, z_s.shape, device), z_s)
+                # (learn_slots: one read-back per clip; with at most 8 labels the masked transfer then stays on the packed code)
+                plan = cwct.bind_style(cwct.learn_slots(cwct.plan_masks(content_seg, style_seg, zc_shape, z_s.shape, device)), z_s)
 
         def transform(z_c, i):
             if args.alpha_c is not None and not masked:
