@@ -235,7 +235,7 @@ def main():
     frame_gbs = frame_bytes * fpg * args.steps / elapsed / 1e9     # per GPU
     per_rank_fps = [round(fpg * args.steps / t, 3) for t in per_rank_s]
 
-    prec_note = {"f16x2": "f32 state / f32 accumulate; fp16 2-term split MFMA in the 256-channel blocks, bf16 3-term split MFMA elsewhere",
+    prec_note = {"f16x2": "f32 state / f32 accumulate; fp16 2-term split MFMA in the 64- and 256-channel blocks, bf16 3-term split MFMA in the 16-channel blocks",
                  "bf16x3": "f32 state / f32 accumulate; bf16 3-term split MFMA", "fp32": "f32"}[args.precision]
     rec = {
         "metric": "stylized frames/sec at 1024x1024 (1/2/4/8 GPU) + % HBM roofline",
@@ -278,6 +278,12 @@ def main():
         dist.destroy_process_group()
 
 
+def conv_terms(f16, cin, cout, stride):
+    """MFMA products issued per algorithmic product: 2 (fp16 2-term) in the 64- and 256-channel blocks of the f16x2 mode,
+    3 (bf16 3-term) in the 16-channel blocks and in the bf16x3 mode."""
+    return 2 if f16 and (cin, cout) != (16, 4) and (cin, cout) != (4, 16) else 3
+
+
 def roofline_from_table(table, n_frames, fpg, H, W, args, _lib):
     """Per-launch roofline of the conv class with the largest total time, and a per-stage summary, from the HIP-event
     table of `n_frames` frames run one at a time (ms are per frame below)."""
@@ -293,9 +299,12 @@ def roofline_from_table(table, n_frames, fpg, H, W, args, _lib):
     _, div, macs = CONV_CLASSES[(cin, cout, stride)]
     flops = 2.0 * 9 * macs * px / div                  # fp32-equivalent conv flops of one launch
     avg_ms = ms / cnt
-    terms = 2 if (f16 and cin >= 64 and cout >= 64 and stride == 1) else 3
+    terms = conv_terms(f16, cin, cout, stride)
     achieved = flops / (avg_ms * 1e-3) / 1e12
-    kname = (f"conv_sp_kernel<{cin},{cout}> (fp16 2-term, LDS-DMA)" if terms == 2 else f"conv kernel <{cin},{cout},s{stride}> (bf16 3-term)")
+    if terms == 2 and cin >= 64 and cout >= 64 and stride == 1:
+        kname = f"conv_sp_kernel<{cin},{cout}> (fp16 2-term, LDS-DMA)"
+    else:
+        kname = f"conv kernel <{cin},{cout},s{stride}> ({'fp16 2-term' if terms == 2 else 'bf16 3-term'})"
     traffic = None
     pmc_path = os.path.join(REPO, "profiles", "r02_pmc_hbm_traffic.json")
     if os.path.exists(pmc_path) and (H, W) == (1024, 1024) and fpg == 1 and args.mode == "photo" and f16:
@@ -327,7 +336,7 @@ def roofline_from_table(table, n_frames, fpg, H, W, args, _lib):
     for (ci, co, st_), (m, c) in per.items():
         stg, dv, mc = CONV_CLASSES[(ci, co, st_)]
         stage_ms[stg] += m
-        t = 2 if (f16 and ci >= 64 and co >= 64 and st_ == 1) else 3
+        t = conv_terms(f16, ci, co, st_)
         stage_issued[stg] += 2.0 * 9 * mc * px / dv * c * t
     for kid, (m, c) in table.items():
         if kid < 65536:

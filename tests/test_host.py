@@ -39,9 +39,10 @@ def test_sizes_and_errors_without_gpu(lib):
     assert lib.vst_block_tmp_bytes(2, 64, 32) == 2 * 64 * 32 * 160
     # packed conv = fp32 taps-major + 2 x bf16 fragment sections (+ 1 fp16 section in the LDS-DMA kernels' K order for the
     # 256-channel blocks' shapes)
-    assert lib.vst_conv_packed_bytes(64, 256) == 9 * 256 * 64 * 4 + 3 * (72 * 4 * 64 * 16)
-    assert lib.vst_conv_packed_bytes(64, 16) == 9 * 16 * 64 * 4 + 2 * (5 * 4 * 64 * 16)
-    assert lib.vst_conv_packed_bytes(4, 16) == ((9 * 16 * 4 * 4 + 255) // 256 * 256) + 2 * (5 * 4 * 16 * 16)
+    # fp32 taps + bf16 hi + bf16 lo + conv3's permuted fp16 (stage-3 shapes) + fp16 in the bf16 order (2-term kernels)
+    assert lib.vst_conv_packed_bytes(64, 256) == 9 * 256 * 64 * 4 + 4 * (72 * 4 * 64 * 16)
+    assert lib.vst_conv_packed_bytes(64, 16) == 9 * 16 * 64 * 4 + 3 * (5 * 4 * 64 * 16)
+    assert lib.vst_conv_packed_bytes(4, 16) == ((9 * 16 * 4 * 4 + 255) // 256 * 256) + 3 * (5 * 4 * 16 * 16)
     assert lib.vst_cwct_stats_workspace_bytes(32, 1 << 20) == 512 * (32 * 32 + 64 + 4) * 4
     # argument validation happens before any launch
     null = C.c_void_p(0)

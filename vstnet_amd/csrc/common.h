@@ -89,14 +89,15 @@ static inline bool vst_shape_ok(int B, int H, int W) {
     return B > 0 && H >= 8 && W >= 8 && (H % 4) == 0 && (W % 4) == 0;
 }
 
-// packed conv weights: [fp32 taps-major | bf16 hi frags | bf16 lo frags]; the stage-3 shapes (cin, cout >= 64) are
-// followed by the fp16 fragments of conv3.hip in its permuted K order
+// packed conv weights: [fp32 taps-major | bf16 hi frags | bf16 lo frags | (stage-3 shapes, cin, cout >= 64: the fp16 fragments
+// of conv3.hip in its permuted K order) | fp16 frags in the bf16 sections' order]
 struct PackedConvLayout {
     int ksteps;       // number of 32-deep K steps (all chunks)
     int coutp;        // cout padded to a multiple of 16
     size_t f32_bytes; // 9*cin*cout*4 rounded up to 256
     size_t frag_bytes;// ksteps*4*coutp*16 (per section)
     int sp_sections;  // 1 for the stage-3 shapes, else 0
+    size_t f16_offset;// byte offset of the fp16 fragments in the bf16 sections' order (the 2-term kernels of conv.hip)
 };
 
 __host__ __device__ inline PackedConvLayout packed_conv_layout(int cout, int cin) {
@@ -106,6 +107,7 @@ __host__ __device__ inline PackedConvLayout packed_conv_layout(int cout, int cin
     p.f32_bytes = ((size_t)9 * cin * cout * 4 + 255) / 256 * 256;
     p.frag_bytes = (size_t)p.ksteps * 4 * p.coutp * 16;
     p.sp_sections = (cin >= 64 && cout >= 64) ? 1 : 0;
+    p.f16_offset = p.f32_bytes + (size_t)(2 + p.sp_sections) * p.frag_bytes;
     return p;
 }
 

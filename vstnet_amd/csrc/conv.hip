@@ -99,8 +99,33 @@ struct ConvCfg {
     static constexpr int A_PLANE = CIN == 4 ? NSLOT * 8 : CIG * NSLOT * 16;
     static constexpr int B_PLANE = KS * 4 * NT * 16;
     static constexpr int LDS_BYTES = 2 * A_PLANE + 2 * B_PLANE;
+    static constexpr int LDS_BYTES_T2 = 2 * A_PLANE + B_PLANE;     // TERMS == 2: one weight plane
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
+
+// TERMS == 3: bf16 hi / lo (3-term product with split weights); TERMS == 2: fp16 hi / lo (2-term product w_hi (x_hi + x_lo),
+// the arithmetic of conv3.hip; values saturate at +-65504 in the hi part)
+__device__ __forceinline__ void split8_f16(const float4 v0, const float4 v1, uint4& hi, uint4& lo) {
+    const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    u32x4 h, l;
+    split8_sp(f, h, l);
+    hi = __builtin_bit_cast(uint4, h);
+    lo = __builtin_bit_cast(uint4, l);
+}
+
+__device__ __forceinline__ void split4_f16(const float4 v, uint2& hi, uint2& lo) {
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+    f16x4 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float c = __builtin_amdgcn_fmed3f(f[i], -65504.f, 65504.f);
+        h[i] = (_Float16)c;
+        l[i] = (_Float16)(f[i] - (float)h[i]);
+    }
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
+}
 
 __device__ __forceinline__ void split8(const float4 v0, const float4 v1, uint4& hi, uint4& lo) {
     const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -186,18 +211,29 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, float* out_img, in
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc, 0, 0, 0);        \
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc, 0, 0, 0)
 
+// the same with the number of terms chosen at compile time: operands are 16-byte containers (bf16x8), read as fp16 when TERMS == 2
+#define MFMA_T(acc, wh, wl, xh, xl)                                                                                          \
+    if constexpr (TERMS == 3) {                                                                                               \
+        MFMA3(acc, wh, wl, xh, xl);                                                                                           \
+    } else {                                                                                                                  \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh), __builtin_bit_cast(f16x8, xl), acc, 0, 0, 0); \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh), __builtin_bit_cast(f16x8, xh), acc, 0, 0, 0); \
+    }
+#define SPLIT8_T(v0_, v1_, h_, l_) { if constexpr (TERMS == 3) split8(v0_, v1_, h_, l_); else split8_f16(v0_, v1_, h_, l_); }
+#define SPLIT4_T(v_, h_, l_) { if constexpr (TERMS == 3) split4(v_, h_, l_); else split4_f16(v_, h_, l_); }
+
 #ifndef VST_EARLY_OLD
 #define VST_EARLY_OLD 1
 #endif
 // ---- generic kernel: one tile per workgroup, staging per input-channel chunk (all shapes) --------------
-template <int CIN, int COUT, int STRIDE, bool IN_STATE, bool OUT_STATE, bool OUT_SP = false>
+template <int CIN, int COUT, int STRIDE, bool IN_STATE, bool OUT_STATE, bool OUT_SP = false, int TERMS = 3>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     using C = ConvCfg<CIN, COUT, STRIDE>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const a_hi = smem;
     unsigned char* const a_lo = smem + C::A_PLANE;
     unsigned char* const b_hi = smem + 2 * C::A_PLANE;
-    unsigned char* const b_lo = b_hi + C::B_PLANE;
+    unsigned char* const b_lo = TERMS == 3 ? b_hi + C::B_PLANE : b_hi;     // TERMS == 2: one weight plane
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
@@ -209,8 +245,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 
     const float* const in_img = a.in + (size_t)b * a.in_img_stride;
     const PackedConvLayout PL = packed_conv_layout(COUT, CIN);
-    const unsigned char* const w_hi = a.packed + PL.f32_bytes;
-    const unsigned char* const w_lo = w_hi + PL.frag_bytes;
+    const unsigned char* const w_hi = a.packed + (TERMS == 3 ? PL.f32_bytes : PL.f16_offset);
+    const unsigned char* const w_lo = w_hi + PL.frag_bytes;                 // (not read when TERMS == 2)
 
     f32x4 acc[C::MR][C::NB];
 #pragma unroll
@@ -240,7 +276,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         const int co = idx % C::NT, r = idx / C::NT;                                               \
         const size_t src = ((size_t)((chunk_) * C::KS * 4 + r) * C::COUTP + co0 + co) * 16;        \
         wreg[it][0] = *(const u32x4*)(w_hi + src);                                                 \
-        wreg[it][1] = *(const u32x4*)(w_lo + src);                                                 \
+        if (TERMS == 3) wreg[it][1] = *(const u32x4*)(w_lo + src);                                 \
     }                                                                                              \
     _Pragma("unroll") for (int it = 0; it < AIT; ++it) {                                           \
         int idx = it * 256 + tid;                                                                  \
@@ -263,13 +299,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         idx = idx < A_ITEMS_T ? idx : A_ITEMS_T - 1;                                               \
         if (CIN == 4) {                                                                            \
             uint2 h, l;                                                                            \
-            split4(F4(areg[it][0]), h, l);                                                         \
+            SPLIT4_T(F4(areg[it][0]), h, l);                                                       \
             *(uint2*)(a_hi + idx * 8) = h;                                                         \
             *(uint2*)(a_lo + idx * 8) = l;                                                         \
         } else {                                                                                   \
             const int cig = idx % C::CIG, slot = idx / C::CIG;                                     \
             uint4 h, l;                                                                            \
-            split8(F4(areg[it][0]), F4(areg[it][NV - 1]), h, l);                                   \
+            SPLIT8_T(F4(areg[it][0]), F4(areg[it][NV - 1]), h, l);                                 \
             *(uint4*)(a_hi + (cig * C::NSLOT + slot) * 16) = h;                                    \
             *(uint4*)(a_lo + (cig * C::NSLOT + slot) * 16) = l;                                    \
         }                                                                                          \
@@ -278,7 +314,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         int idx = it * 256 + tid;                                                                  \
         idx = idx < W_ITEMS_T ? idx : W_ITEMS_T - 1;                                               \
         *(u32x4*)(b_hi + idx * 16) = wreg[it][0];                                                  \
-        *(u32x4*)(b_lo + idx * 16) = wreg[it][1];                                                  \
+        if (TERMS == 3) *(u32x4*)(b_lo + idx * 16) = wreg[it][1];                                  \
     }
 
     float* const out_img = a.out + (size_t)b * a.out_img_stride;
@@ -308,7 +344,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             for (int n = 0; n < C::NB; ++n) {
                 const int boff = ((ks * 4 + kg) * C::NT + n * 16 + lrow) * 16;
                 wh[n] = __builtin_bit_cast(bf16x8, *(const uint4*)(b_hi + boff));
-                wl[n] = __builtin_bit_cast(bf16x8, *(const uint4*)(b_lo + boff));
+                if (TERMS == 3) wl[n] = __builtin_bit_cast(bf16x8, *(const uint4*)(b_lo + boff)); else wl[n] = wh[n];
             }
 #pragma unroll
             for (int m = 0; m < C::MR; ++m) {
@@ -339,7 +375,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                     xl = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
                 }
 #pragma unroll
-                for (int n = 0; n < C::NB; ++n) { MFMA3(acc[m][n], wh[n], wl[n], xh, xl); }
+                for (int n = 0; n < C::NB; ++n) { MFMA_T(acc[m][n], wh[n], wl[n], xh, xl); }
             }
         }
         if (chunk + 1 < C::NCHUNK) {
@@ -411,7 +447,7 @@ __device__ __forceinline__ void read_x_small(const unsigned char* img_hi, const 
     }
 }
 
-template <int MID, int CH>
+template <int MID, int CH, int TERMS = 3>
 struct PairCfg {
     using C7 = ConvCfg<MID, CH, 1>;
     static constexpr int R1 = 20, N1SLOT = 400, RW = 18, NPX = 324, NBLK = (NPX + 15) / 16;   // h1 region, h2 ring region
@@ -420,14 +456,15 @@ struct PairCfg {
     // MID == 16: conv.7's 40 KB of weights take over the h1 region + conv.4 weights once conv.4 is done (62 KB, two
     // workgroups per CU); MID == 4: everything is small, conv.7's weights get their own region (one barrier fewer)
     static constexpr bool ALIAS = MID == 16;
-    static constexpr int H1W4 = 2 * H1_PLANE + 2 * W4_PLANE;
-    static constexpr int U_BYTES = ALIAS ? (H1W4 > 2 * C7::B_PLANE ? H1W4 : 2 * C7::B_PLANE) : H1W4 + 2 * C7::B_PLANE;
+    static constexpr int WPL = TERMS == 3 ? 2 : 1;            // weight planes in LDS (hi + lo, or the fp16 plane alone)
+    static constexpr int H1W4 = 2 * H1_PLANE + WPL * W4_PLANE;
+    static constexpr int U_BYTES = ALIAS ? (H1W4 > WPL * C7::B_PLANE ? H1W4 : WPL * C7::B_PLANE) : H1W4 + WPL * C7::B_PLANE;
     static constexpr int LDS_BYTES = 2 * C7::A_PLANE + U_BYTES;
 };
 
-template <int MID, int CH>
+template <int MID, int CH, int TERMS = 3>
 __global__ __launch_bounds__(256) void conv_pair_kernel(const ConvArgs a) {
-    using P = PairCfg<MID, CH>;
+    using P = PairCfg<MID, CH, TERMS>;
     using C = typename P::C7;
     static_assert(C::NCHUNK == 1 && C::NCOT == 1, "single-chunk shapes");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -435,11 +472,11 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const ConvArgs a) {
     unsigned char* const a_lo = smem + C::A_PLANE;
     unsigned char* const u0 = smem + 2 * C::A_PLANE;
     unsigned char* const b_hi = P::ALIAS ? u0 : u0 + P::H1W4;   // conv.7 weights (aliased: valid after conv.4 is done)
-    unsigned char* const b_lo = b_hi + C::B_PLANE;
+    unsigned char* const b_lo = TERMS == 3 ? b_hi + C::B_PLANE : b_hi;
     unsigned char* const h1_hi = u0;                         // h1 region + conv.4 weights (before)
     unsigned char* const h1_lo = u0 + P::H1_PLANE;
     unsigned char* const w4s_hi = u0 + 2 * P::H1_PLANE;
-    unsigned char* const w4s_lo = w4s_hi + P::W4_PLANE;
+    unsigned char* const w4s_lo = TERMS == 3 ? w4s_hi + P::W4_PLANE : w4s_hi;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
@@ -451,9 +488,9 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const ConvArgs a) {
     const float* const in_img = a.in + (size_t)b * a.in_img_stride;
     float* const out_img = a.out + (size_t)b * a.out_img_stride;
     const PackedConvLayout PL7 = packed_conv_layout(CH, MID), PL4 = packed_conv_layout(MID, MID);
-    const unsigned char* const w7_hi = a.packed + PL7.f32_bytes;
-    const unsigned char* const w7_lo = w7_hi + PL7.frag_bytes;
-    const unsigned char* const w4_hi = a.packed1 + PL4.f32_bytes;
+    const unsigned char* const w7_hi = a.packed + (TERMS == 3 ? PL7.f32_bytes : PL7.f16_offset);
+    const unsigned char* const w7_lo = w7_hi + PL7.frag_bytes;              // (the lo planes are not read when TERMS == 2)
+    const unsigned char* const w4_hi = a.packed1 + (TERMS == 3 ? PL4.f32_bytes : PL4.f16_offset);
     const unsigned char* const w4_lo = w4_hi + PL4.frag_bytes;
 
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -468,7 +505,7 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const ConvArgs a) {
         int idx = it * 256 + tid;
         idx = idx < W4_ITEMS ? idx : W4_ITEMS - 1;
         w4reg[it][0] = *(const u32x4*)(w4_hi + (size_t)idx * 16);      // coutp == 16: fragment order is already [r][co]
-        w4reg[it][1] = *(const u32x4*)(w4_lo + (size_t)idx * 16);
+        if (TERMS == 3) w4reg[it][1] = *(const u32x4*)(w4_lo + (size_t)idx * 16);
     }
 #pragma unroll
     for (int it = 0; it < H1IT; ++it) {
@@ -488,7 +525,7 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const ConvArgs a) {
         const int co = idx % C::NT, r = idx / C::NT;
         const size_t src = ((size_t)r * C::COUTP + co) * 16;
         w7reg[it][0] = *(const u32x4*)(w7_hi + src);
-        w7reg[it][1] = *(const u32x4*)(w7_lo + src);
+        if (TERMS == 3) w7reg[it][1] = *(const u32x4*)(w7_lo + src);
     }
     float4 bias[C::NB], old[C::MR][C::NB];
     const bool interior = ty0 + C::TH <= H && tx0 + C::TW <= W;
@@ -506,13 +543,13 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const ConvArgs a) {
         idx = idx < H1_ITEMS ? idx : H1_ITEMS - 1;
         if (MID == 4) {
             uint2 h, l;
-            split4(F4(hreg[it][0]), h, l);
+            SPLIT4_T(F4(hreg[it][0]), h, l);
             *(uint2*)(h1_hi + idx * 8) = h;
             *(uint2*)(h1_lo + idx * 8) = l;
         } else {
             const int cig = idx % C::CIG, slot = idx / C::CIG;
             uint4 h, l;
-            split8(F4(hreg[it][0]), F4(hreg[it][NV - 1]), h, l);
+            SPLIT8_T(F4(hreg[it][0]), F4(hreg[it][NV - 1]), h, l);
             *(uint4*)(h1_hi + (cig * P::N1SLOT + slot) * 16) = h;
             *(uint4*)(h1_lo + (cig * P::N1SLOT + slot) * 16) = l;
         }
@@ -523,14 +560,14 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const ConvArgs a) {
         int idx = it * 256 + tid;
         idx = idx < W4_ITEMS ? idx : W4_ITEMS - 1;
         *(u32x4*)(w4s_hi + idx * 16) = w4reg[it][0];
-        *(u32x4*)(w4s_lo + idx * 16) = w4reg[it][1];
+        if (TERMS == 3) *(u32x4*)(w4s_lo + idx * 16) = w4reg[it][1];
     }
 #define LAND_W7()                                                                                  \
     _Pragma("unroll") for (int it = 0; it < W7IT; ++it) {                                          \
         int idx = it * 256 + tid;                                                                  \
         idx = idx < W7_ITEMS ? idx : W7_ITEMS - 1;                                                 \
         *(u32x4*)(b_hi + idx * 16) = w7reg[it][0];                                                 \
-        *(u32x4*)(b_lo + idx * 16) = w7reg[it][1];                                                 \
+        if (TERMS == 3) *(u32x4*)(b_lo + idx * 16) = w7reg[it][1];                                 \
     }
     if (!P::ALIAS) { LAND_W7(); }
     __syncthreads();
@@ -577,7 +614,7 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const ConvArgs a) {
                 for (int u = 0; u < 2; ++u) {
                     bf16x8 xh, xl;
                     read_x_small<MID>(h1_hi, h1_lo, P::N1SLOT, ryv[u] * P::R1 + rxv[u], P::R1, ks, kg, xh, xl);
-                    MFMA3(acc4[u], wh, wl, xh, xl);
+                    MFMA_T(acc4[u], wh, wl, xh, xl);
                 }
             }
 #pragma unroll
@@ -588,7 +625,7 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const ConvArgs a) {
                 v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
                 v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
                 uint2 h, l;
-                split4(v, h, l);
+                SPLIT4_T(v, h, l);
 #define PAIR_PUT(slot_)                                                                            \
                 if (MID == 4) {                                                                    \
                     *(uint2*)(a_hi + (slot_) * 8) = h;                                             \
@@ -647,7 +684,7 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const ConvArgs a) {
             bf16x8 xh, xl;
             read_x_small<MID>(a_hi, a_lo, C::NSLOT, slot_base + m * C::IW, C::IW, ks, kg, xh, xl);
 #pragma unroll
-            for (int n = 0; n < C::NB; ++n) { MFMA3(acc[m][n], wh[n], wl[n], xh, xl); }
+            for (int n = 0; n < C::NB; ++n) { MFMA_T(acc[m][n], wh[n], wl[n], xh, xl); }
         }
     }
     load_bias<CH, C::NB>(a, 4 * kg, bias);
@@ -946,13 +983,19 @@ static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) 
         kern<<<dim3((t.tiles_total + 7) / 8 * 8), C::NTHR, C::LDS_BYTES, st>>>(t);
     } else {
         using C = ConvCfg<CIN, COUT, STRIDE>;
-        auto kern = conv_mfma_kernel<CIN, COUT, STRIDE, IN_STATE, OUT_STATE>;
-        static std::atomic<unsigned> attr_done{0};
-        if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)(C::LDS_BYTES), &attr_done)) return rc_;
+        // f16x2: the convs of the 64-channel (stage-2) blocks run the 2-term fp16 product as well (one weight plane in LDS:
+        // three workgroups per CU instead of two, a third fewer MFMAs); the 16-channel blocks stay on bf16 x 3
+        constexpr bool T2_SHAPE = (CIN == 64 && COUT == 16) || (CIN == 16 && COUT == 16 && STRIDE == 2);
+        const bool t2 = T2_SHAPE && precision == VST_PREC_F16X2;
+        auto kern = t2 ? conv_mfma_kernel<CIN, COUT, STRIDE, IN_STATE, OUT_STATE, false, T2_SHAPE ? 2 : 3>
+                       : conv_mfma_kernel<CIN, COUT, STRIDE, IN_STATE, OUT_STATE, false, 3>;
+        const int lds = t2 ? C::LDS_BYTES_T2 : C::LDS_BYTES;
+        static std::atomic<unsigned> attr_done[2];
+        if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, lds, &attr_done[t2 ? 1 : 0])) return rc_;
         ConvArgs t = a;
         t.tiles_x = (a.Wout + C::TW - 1) / C::TW; t.tiles_y = (a.Hout + C::TH - 1) / C::TH;
         t.tiles_total = t.tiles_x * t.tiles_y * B * C::NCOT;
-        kern<<<dim3((t.tiles_total + 7) / 8 * 8), 256, C::LDS_BYTES, st>>>(t);
+        kern<<<dim3((t.tiles_total + 7) / 8 * 8), 256, lds, st>>>(t);
     }
     VST_RETURN_IF_LAUNCH_FAILED();
     return VST_OK;
@@ -962,13 +1005,13 @@ static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) 
 static int launch_conv_s2_planes(const ConvArgs& a, int B, hipStream_t st) {
     using C = ConvCfg<64, 64, 2>;
     vst_prof_scope prof(VST_KERNEL_ID(64, 64, 2), st);
-    auto kern = conv_mfma_kernel<64, 64, 2, true, false, true>;
+    auto kern = conv_mfma_kernel<64, 64, 2, true, false, true, 2>;      // (the f16x2 path: 2-term fp16 like the rest of the block)
     static std::atomic<unsigned> attr_done{0};
-    if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)(C::LDS_BYTES), &attr_done)) return rc_;
+    if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)(C::LDS_BYTES_T2), &attr_done)) return rc_;
     ConvArgs t = a;
     t.tiles_x = (a.Wout + C::TW - 1) / C::TW; t.tiles_y = (a.Hout + C::TH - 1) / C::TH;
     t.tiles_total = t.tiles_x * t.tiles_y * B * C::NCOT;
-    kern<<<dim3((t.tiles_total + 7) / 8 * 8), 256, C::LDS_BYTES, st>>>(t);
+    kern<<<dim3((t.tiles_total + 7) / 8 * 8), 256, C::LDS_BYTES_T2, st>>>(t);
     VST_RETURN_IF_LAUNCH_FAILED();
     return VST_OK;
 }
@@ -977,15 +1020,17 @@ static int launch_conv_s2_planes(const ConvArgs& a, int B, hipStream_t st) {
 #define VST_PAIR 1
 #endif
 template <int MID, int CH>
-static int launch_pair(const ConvArgs& a, int B, hipStream_t st) {
-    using P = PairCfg<MID, CH>;
+static int launch_pair(const ConvArgs& a, int B, int precision, hipStream_t st) {
+    constexpr int T2 = MID == 16 ? 2 : 3;                   // f16x2: the 64-channel blocks' pair runs the 2-term fp16 product
+    const bool t2 = T2 == 2 && precision == VST_PREC_F16X2;
     vst_prof_scope prof(VST_KERNEL_ID(MID, CH, 1), st);
-    auto kern = conv_pair_kernel<MID, CH>;
-    static std::atomic<unsigned> attr_done{0};
-    if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)(P::LDS_BYTES), &attr_done)) return rc_;
+    auto kern = t2 ? conv_pair_kernel<MID, CH, T2> : conv_pair_kernel<MID, CH, 3>;
+    const int lds = t2 ? PairCfg<MID, CH, T2>::LDS_BYTES : PairCfg<MID, CH, 3>::LDS_BYTES;
+    static std::atomic<unsigned> attr_done[2];
+    if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, lds, &attr_done[t2 ? 1 : 0])) return rc_;
     ConvArgs t = a;
     t.tiles_x = (a.Wout + 15) / 16; t.tiles_y = (a.Hout + 15) / 16; t.tiles_total = t.tiles_x * t.tiles_y * B;
-    kern<<<dim3((t.tiles_total + 7) / 8 * 8), 256, P::LDS_BYTES, st>>>(t);
+    kern<<<dim3((t.tiles_total + 7) / 8 * 8), 256, lds, st>>>(t);
     VST_RETURN_IF_LAUNCH_FAILED();
     return VST_OK;
 }
@@ -1033,7 +1078,7 @@ static int run_block(const vst_block_weights* w, int direction, int precision, f
             a.packed = (const unsigned char*)w->conv[2].packed; a.bias = w->conv[2].bias;
             a.packed1 = (const unsigned char*)w->conv[1].packed; a.bias1 = w->conv[1].bias;
             a.sign = direction > 0 ? 1.f : -1.f;
-            return launch_pair<MID, CH>(a, B, st);
+            return launch_pair<MID, CH>(a, B, precision, st);
         }
     }
     // conv.4: h1 -> h2 (ReLU)

@@ -243,6 +243,7 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, int cout, int cin,
         const __bf16 lo = (__bf16)(v - (float)hi);
         ((__bf16*)(packed + L.f32_bytes))[idx] = hi;
         ((__bf16*)(packed + L.f32_bytes + L.frag_bytes))[idx] = lo;
+        ((_Float16*)(packed + L.f16_offset))[idx] = (_Float16)v;      // the 2-term kernels: w rounded to fp16, once
         if (L.sp_sections) {
             // conv3.hip: the 8 channels of k-group kg are the ones a producer lane holds, {4kg + r, 16 + 4kg + r} of the chunk
             const int cip = (ks / 9) * 32 + (j >> 2) * 16 + kg * 4 + (j & 3);
@@ -271,7 +272,7 @@ const char* vst_error_string(int code) {
 
 size_t vst_conv_packed_bytes(int cout, int cin) {
     const PackedConvLayout L = packed_conv_layout(cout, cin);
-    return L.f32_bytes + (2 + L.sp_sections) * L.frag_bytes;
+    return L.f16_offset + L.frag_bytes;
 }
 
 int vst_pack_conv(const float* w, int cout, int cin, void* packed, void* stream) {
