@@ -463,7 +463,7 @@ struct PairCfg {
 };
 
 template <int MID, int CH, int TERMS = 3>
-__global__ __launch_bounds__(256) void conv_pair_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, (MID == 16 && TERMS == 2) ? 3 : 1) void conv_pair_kernel(const ConvArgs a) {
     using P = PairCfg<MID, CH, TERMS>;
     using C = typename P::C7;
     static_assert(C::NCHUNK == 1 && C::NCOT == 1, "single-chunk shapes");
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const ConvArgs a) {
     }
     float4 bias[C::NB], old[C::MR][C::NB];
     const bool interior = ty0 + C::TH <= H && tx0 + C::TW <= W;
-    constexpr bool EARLY_OLD = C::MR * C::NB >= 16;          // as in the generic kernel: not where it costs occupancy
+    constexpr bool EARLY_OLD = C::MR * C::NB >= 16 && TERMS == 3;   // (2-term form: three workgroups per CU need <= 168 VGPRs)
 #define PAIR_FETCH_OLD()                                                                                         \
     if (interior) load_old<CH, C::MR, C::NB, true>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, 4 * kg, old);   \
     else load_old<CH, C::MR, C::NB>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, 4 * kg, old);
