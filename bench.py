@@ -235,7 +235,7 @@ def main():
     frame_gbs = frame_bytes * fpg * args.steps / elapsed / 1e9     # per GPU
     per_rank_fps = [round(fpg * args.steps / t, 3) for t in per_rank_s]
 
-    prec_note = {"f16x2": "f32 state / f32 accumulate; fp16 2-term split MFMA in the 64- and 256-channel blocks, bf16 3-term split MFMA in the 16-channel blocks",
+    prec_note = {"f16x2": "f32 state / f32 accumulate; fp16 2-term split MFMA: w_hi (x_hi + x_lo)",
                  "bf16x3": "f32 state / f32 accumulate; bf16 3-term split MFMA", "fp32": "f32"}[args.precision]
     rec = {
         "metric": "stylized frames/sec at 1024x1024 (1/2/4/8 GPU) + % HBM roofline",
@@ -279,9 +279,8 @@ def main():
 
 
 def conv_terms(f16, cin, cout, stride):
-    """MFMA products issued per algorithmic product: 2 (fp16 2-term) in the 64- and 256-channel blocks of the f16x2 mode,
-    3 (bf16 3-term) in the 16-channel blocks and in the bf16x3 mode."""
-    return 2 if f16 and (cin, cout) != (16, 4) and (cin, cout) != (4, 16) else 3
+    """MFMA products issued per algorithmic product: 2 (fp16 2-term) in the f16x2 mode, 3 (bf16 3-term) in the bf16x3 mode."""
+    return 2 if f16 else 3
 
 
 def roofline_from_table(table, n_frames, fpg, H, W, args, _lib):

@@ -40,10 +40,10 @@ extern "C" {
 /* conv arithmetic */
 #define VST_PREC_BF16X3 0   /* bf16 MFMA, hi/lo split operands (3 products), fp32 accumulate: ~3e-6 rel */
 #define VST_PREC_FP32 1     /* plain fp32 FMA direct convolution (diagnostic / cross-check, slow) */
-#define VST_PREC_F16X2 2    /* as BF16X3 in the 16-channel blocks; the 64- and 256-channel blocks (97 % of the flops): fp16
-                               MFMA, w_hi * (x_hi + x_lo) (2 products; weights rounded to fp16 once); in the 256-channel
-                               stride-1 blocks the operands are pre-split in HBM and staged by LDS-DMA:
-                               ~1.3e-4 rel on the code, ~3e-6 on a stylised frame */
+#define VST_PREC_F16X2 2    /* fp16 MFMA, w_hi * (x_hi + x_lo): 2 products, activations split into fp16 hi + lo (22 bits),
+                               weights rounded to fp16 once at pack time; in the 256-channel stride-1 blocks the
+                               operands are pre-split in HBM and staged by LDS-DMA:
+                               ~1.5e-4 rel on the code, ~4e-6 on a stylised frame */
 
 #define VST_NUM_BLOCKS 32   /* 30 stack blocks + 2 channel_reduction blocks */
 

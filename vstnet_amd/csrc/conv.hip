@@ -983,9 +983,9 @@ static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) 
         kern<<<dim3((t.tiles_total + 7) / 8 * 8), C::NTHR, C::LDS_BYTES, st>>>(t);
     } else {
         using C = ConvCfg<CIN, COUT, STRIDE>;
-        // f16x2: the convs of the 64-channel (stage-2) blocks run the 2-term fp16 product as well (one weight plane in LDS:
-        // three workgroups per CU instead of two, a third fewer MFMAs); the 16-channel blocks stay on bf16 x 3
-        constexpr bool T2_SHAPE = (CIN == 64 && COUT == 16) || (CIN == 16 && COUT == 16 && STRIDE == 2);
+        // f16x2: the convs of the 16- and 64-channel blocks run the 2-term fp16 product as well (one weight plane in LDS: one
+        // more workgroup per CU, a third fewer MFMAs)
+        constexpr bool T2_SHAPE = (CIN == 64 && COUT == 16) || (CIN == 16 && COUT == 16 && STRIDE == 2) || (CIN == 16 && COUT == 4);
         const bool t2 = T2_SHAPE && precision == VST_PREC_F16X2;
         auto kern = t2 ? conv_mfma_kernel<CIN, COUT, STRIDE, IN_STATE, OUT_STATE, false, T2_SHAPE ? 2 : 3>
                        : conv_mfma_kernel<CIN, COUT, STRIDE, IN_STATE, OUT_STATE, false, 3>;
@@ -1021,7 +1021,7 @@ static int launch_conv_s2_planes(const ConvArgs& a, int B, hipStream_t st) {
 #endif
 template <int MID, int CH>
 static int launch_pair(const ConvArgs& a, int B, int precision, hipStream_t st) {
-    constexpr int T2 = MID == 16 ? 2 : 3;                   // f16x2: the 64-channel blocks' pair runs the 2-term fp16 product
+    constexpr int T2 = 2;                                    // f16x2: the pair runs the 2-term fp16 product
     const bool t2 = T2 == 2 && precision == VST_PREC_F16X2;
     vst_prof_scope prof(VST_KERNEL_ID(MID, CH, 1), st);
     auto kern = t2 ? conv_pair_kernel<MID, CH, T2> : conv_pair_kernel<MID, CH, 3>;
