@@ -82,13 +82,13 @@ __device__ __forceinline__ bool xcd_tile(const ConvArgs& a, int& bx, int& by, in
     return true;
 }
 
-template <int CIN, int COUT, int STRIDE>
+template <int CIN, int COUT, int STRIDE, int MRO = 0>      // MRO: tile rows per wave if not the default
 struct ConvCfg {
     static constexpr int NT = COUT >= 64 ? 64 : 16;      // output channels per workgroup
     static constexpr int NB = NT / 16;                   // 16-wide N blocks per wave
     static constexpr int COUTP = (COUT + 15) / 16 * 16;
     static constexpr int NCOT = COUTP / NT;              // co tiles (grid.z factor)
-    static constexpr int MR = STRIDE == 2 ? 2 : 4;       // tile rows (16-pixel M blocks) per wave
+    static constexpr int MR = MRO ? MRO : (STRIDE == 2 ? 2 : 4);   // tile rows (16-pixel M blocks) per wave
     static constexpr int TH = 4 * MR, TW = 16;
     static constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3;
     static constexpr int NSLOT = (IH * IW + 15) / 16 * 16;
@@ -447,10 +447,11 @@ __device__ __forceinline__ void read_x_small(const unsigned char* img_hi, const 
     }
 }
 
-template <int MID, int CH, int TERMS = 3>
+template <int MID, int CH, int TERMS = 3, int MR = 4>
 struct PairCfg {
-    using C7 = ConvCfg<MID, CH, 1>;
-    static constexpr int R1 = 20, N1SLOT = 400, RW = 18, NPX = 324, NBLK = (NPX + 15) / 16;   // h1 region, h2 ring region
+    using C7 = ConvCfg<MID, CH, 1, MR>;
+    // h1 region (TH + 4 rows x 20 columns), h2 ring region (TH + 2 rows x 18 columns) of a TH x 16 tile, TH = 4 MR
+    static constexpr int R1 = 20, N1SLOT = (4 * MR + 4) * R1, RW = 18, RH = 4 * MR + 2, NPX = RH * RW, NBLK = (NPX + 15) / 16;
     static constexpr int H1_PLANE = MID == 4 ? N1SLOT * 8 : C7::CIG * N1SLOT * 16;
     static constexpr int W4_PLANE = C7::KS * 4 * 16 * 16;
     // MID == 16: conv.7's 40 KB of weights take over the h1 region + conv.4 weights once conv.4 is done (62 KB, two
@@ -462,9 +463,9 @@ struct PairCfg {
     static constexpr int LDS_BYTES = 2 * C7::A_PLANE + U_BYTES;
 };
 
-template <int MID, int CH, int TERMS = 3>
+template <int MID, int CH, int TERMS = 3, int MR = 4>
 __global__ __launch_bounds__(256, (MID == 16 && TERMS == 2) ? 3 : 1) void conv_pair_kernel(const ConvArgs a) {
-    using P = PairCfg<MID, CH, TERMS>;
+    using P = PairCfg<MID, CH, TERMS, MR>;
     using C = typename P::C7;
     static_assert(C::NCHUNK == 1 && C::NCOT == 1, "single-chunk shapes");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(256, (MID == 16 && TERMS == 2) ? 3 : 1) void conv_p
     {
         float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (4 * kg < MID) b4 = *(const float4*)(a.bias1 + 4 * kg);
-        const bool ring_inside = ty0 >= 1 && tx0 >= 1 && ty0 + 17 <= H && tx0 + 17 <= W;
+        const bool ring_inside = ty0 >= 1 && tx0 >= 1 && ty0 + C::TH + 1 <= H && tx0 + 17 <= W;
         constexpr bool HOIST = MID == 4;                        // conv.4's fragments are the same for every pixel block;
         bf16x8 w4h[HOIST ? C::KS : 1], w4l[HOIST ? C::KS : 1];   // keep them in registers where there is room
         if (HOIST) {
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(256, (MID == 16 && TERMS == 2) ? 3 : 1) void conv_p
                         // same in x; where no mirror applies the same slot is written again
                         const int my = gy == 1 ? -2 : (gy == H - 2 ? 2 : 0), mx = gx == 1 ? -2 : (gx == W - 2 ? 2 : 0);
                         int sy = ry + my, sx = rx + mx;
-                        sy = (sy < 0 || sy >= P::RW) ? ry : sy;
+                        sy = (sy < 0 || sy >= P::RH) ? ry : sy;
                         sx = (sx < 0 || sx >= P::RW) ? rx : sx;
                         PAIR_PUT(ry * C::IW + rx);
                         PAIR_PUT(sy * C::IW + rx);
@@ -1019,17 +1020,24 @@ static int launch_conv_s2_planes(const ConvArgs& a, int B, hipStream_t st) {
 #ifndef VST_PAIR
 #define VST_PAIR 1
 #endif
+#ifndef VST_PAIR_MR2
+#define VST_PAIR_MR2 0       // 1: the 64-channel 2-term pair on 8 x 16 tiles (measured, not kept: DESIGN.md)
+#endif
 template <int MID, int CH>
 static int launch_pair(const ConvArgs& a, int B, int precision, hipStream_t st) {
     constexpr int T2 = 2;                                    // f16x2: the pair runs the 2-term fp16 product
     const bool t2 = T2 == 2 && precision == VST_PREC_F16X2;
     vst_prof_scope prof(VST_KERNEL_ID(MID, CH, 1), st);
-    auto kern = t2 ? conv_pair_kernel<MID, CH, T2> : conv_pair_kernel<MID, CH, 3>;
-    const int lds = t2 ? PairCfg<MID, CH, T2>::LDS_BYTES : PairCfg<MID, CH, 3>::LDS_BYTES;
+    // (-DVST_PAIR_MR2=1: the 64-channel blocks' 2-term pair on 8 x 16 tiles - 33 KB of LDS, 96 VGPRs, four workgroups per CU,
+    // eight per CU and launch at 1024 x 1024 in two even rounds instead of 3 + 1: 7 % faster alone, 0.6 % slower in the frame)
+    constexpr int MRT = (MID == 16 && VST_PAIR_MR2) ? 2 : 4;
+    auto kern = t2 ? conv_pair_kernel<MID, CH, T2, MRT> : conv_pair_kernel<MID, CH, 3, 4>;
+    const int lds = t2 ? PairCfg<MID, CH, T2, MRT>::LDS_BYTES : PairCfg<MID, CH, 3, 4>::LDS_BYTES;
+    const int th = t2 ? 4 * MRT : 16;
     static std::atomic<unsigned> attr_done[2];
     if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, lds, &attr_done[t2 ? 1 : 0])) return rc_;
     ConvArgs t = a;
-    t.tiles_x = (a.Wout + 15) / 16; t.tiles_y = (a.Hout + 15) / 16; t.tiles_total = t.tiles_x * t.tiles_y * B;
+    t.tiles_x = (a.Wout + 15) / 16; t.tiles_y = (a.Hout + th - 1) / th; t.tiles_total = t.tiles_x * t.tiles_y * B;
     kern<<<dim3((t.tiles_total + 7) / 8 * 8), 256, lds, st>>>(t);
     VST_RETURN_IF_LAUNCH_FAILED();
     return VST_OK;
