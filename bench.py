@@ -58,7 +58,7 @@ def parse_args(argv=None):
                     "per-pixel random labels (the worst case for any per-label tile skipping)")
     ap.add_argument("--mode", default="photo", choices=["photo", "art"])
     ap.add_argument("--frames-per-gpu", type=int, default=1)
-    ap.add_argument("--precision", default="f16x2", choices=["f16x2", "bf16x3", "fp32"])
+    ap.add_argument("--precision", default="f16x2h", choices=["f16x2", "f16x2h", "bf16x3", "fp32"])
     ap.add_argument("--recompute-style", action="store_true", help="re-encode + re-factor the style every frame "
                     "(the reference's video loop, video_transfer.py:195) instead of caching it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -236,6 +236,8 @@ def main():
     per_rank_fps = [round(fpg * args.steps / t, 3) for t in per_rank_s]
 
     prec_note = {"f16x2": "f32 state / f32 accumulate; fp16 2-term split MFMA: w_hi (x_hi + x_lo)",
+                 "f16x2h": "f32 state / f32 accumulate; fp16 2-term split MFMA: w_hi (x_hi + x_lo); the 64-channel input of the "
+                           "256-channel blocks' last conv as one fp16 plane (1 MFMA per product there)",
                  "bf16x3": "f32 state / f32 accumulate; bf16 3-term split MFMA", "fp32": "f32"}[args.precision]
     rec = {
         "metric": "stylized frames/sec at 1024x1024 (1/2/4/8 GPU) + % HBM roofline",
@@ -279,7 +281,10 @@ def main():
 
 
 def conv_terms(f16, cin, cout, stride):
-    """MFMA products issued per algorithmic product: 2 (fp16 2-term) in the f16x2 mode, 3 (bf16 3-term) in the bf16x3 mode."""
+    """MFMA products issued per algorithmic product: 2 (fp16 2-term) in the f16x2 modes - 1 in the 256-channel blocks' last conv
+    under f16x2h, whose input is one fp16 plane -, 3 (bf16 3-term) in the bf16x3 mode."""
+    if f16 == "h" and (cin, cout, stride) == (64, 256, 1):
+        return 1
     return 2 if f16 else 3
 
 
@@ -287,7 +292,7 @@ def roofline_from_table(table, n_frames, fpg, H, W, args, _lib):
     """Per-launch roofline of the conv class with the largest total time, and a per-stage summary, from the HIP-event
     table of `n_frames` frames run one at a time (ms are per frame below)."""
     px = fpg * H * W                                   # full-resolution pixels per frame batch
-    f16 = args.precision == "f16x2"
+    f16 = "h" if args.precision == "f16x2h" else args.precision == "f16x2"      # truthy for both fp16 modes
     per = {}                                           # (cin, cout, stride) -> (ms per frame, launches per frame)
     for kid, (ms, cnt) in table.items():
         if kid >= 65536:
@@ -300,8 +305,8 @@ def roofline_from_table(table, n_frames, fpg, H, W, args, _lib):
     avg_ms = ms / cnt
     terms = conv_terms(f16, cin, cout, stride)
     achieved = flops / (avg_ms * 1e-3) / 1e12
-    if terms == 2 and cin >= 64 and cout >= 64 and stride == 1:
-        kname = f"conv_sp_kernel<{cin},{cout}> (fp16 2-term, LDS-DMA)"
+    if terms <= 2 and cin >= 64 and cout >= 64 and stride == 1:
+        kname = f"conv_sp_kernel<{cin},{cout}> (fp16 {terms}-term, LDS-DMA)"
     else:
         kname = f"conv kernel <{cin},{cout},s{stride}> ({'fp16 2-term' if terms == 2 else 'bf16 3-term'})"
     traffic = None
@@ -311,7 +316,10 @@ def roofline_from_table(table, n_frames, fpg, H, W, args, _lib):
         hit = [v for n, v in k.items() if f"<{cin}, {cout}," in n and "conv_sp" in n]
         traffic = hit[0]["hbm_bytes_per_launch"] if hit else None
     # Both roofs of the launch; the binding one (the larger minimum time) is reported as `bound` / `achieved` / `frac`.
-    nbytes = CONV_BYTES[(cin, cout, stride)] * px / div
+    per_px = CONV_BYTES[(cin, cout, stride)]
+    if f16 == "h" and (cin, cout, stride) in ((64, 64, 1), (64, 256, 1)):
+        per_px -= 128                                      # h2 is written / read as one fp16 plane: 128 instead of 256 B per pixel
+    nbytes = per_px * px / div
     tbps = nbytes / (avg_ms * 1e-3) / 1e12
     t_hbm, t_mfma = nbytes / (HBM_PEAK_GBS * 1e9), flops / (MFMA_16BIT_PEAK_TFLOPS * 1e12)
     both = {"hbm": {"algorithmic_bytes": int(nbytes), "achieved_GBps": round(tbps * 1e3, 1), "frac": round(tbps * 1e3 / HBM_PEAK_GBS, 4)},

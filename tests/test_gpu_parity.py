@@ -127,10 +127,15 @@ def test_block_golden(L, golden, name, k, channel, stride, precision, tol):
 
 
 # ------------------------------------------------------------------------------------------- network
-NET_TOL = {"fp32": 5e-6, "bf16x3": TIGHT, "f16x2": 2e-4}
+# f16x2: weights rounded to fp16 once (measured 1.44e-4 rel-L2 / 1.51e-4 max-rel on the 1024x1024 code); f16x2h: in addition the
+# 64-channel input of the 256-channel blocks' last conv rounded to fp16 (1.54e-4 / 1.80e-4).  Both far inside the 1e-3 budget.
+NET_TOL = {"fp32": 5e-6, "bf16x3": TIGHT, "f16x2": 2e-4, "f16x2h": 2.5e-4}
+# inverse(forward(x)): the same deterministic F in both directions; f16x2h's rounding of an intermediate makes F a step function
+# of its input, so the fp32 rounding of the recovered states is amplified a little (measured 1.3e-5 max-rel)
+RT_TOL = {"fp32": 5e-6, "bf16x3": 5e-6, "f16x2": 5e-6, "f16x2h": 3e-5}
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x2"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x2", "f16x2h"])
 @pytest.mark.parametrize("mode", ["photo", "art"])
 def test_network_golden(golden, mode, precision):
     g = golden(f"net_{mode}")
@@ -144,10 +149,10 @@ def test_network_golden(golden, mode, precision):
         y = net(T(g[f"zp_{tag}"]).cuda(), forward=False)
         assert_close(y, T(g[f"y_{tag}"]), tol, f"{mode}.{tag} inverse")
         rec = net(z, forward=False)
-        assert_close(rec, x, 5e-6, f"{mode}.{tag} inverse(forward(x))")
+        assert_close(rec, x, RT_TOL[precision], f"{mode}.{tag} inverse(forward(x))")
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2", "f16x2h"])
 @pytest.mark.parametrize("mode,shape", [("photo", (1, 72, 104)), ("photo", (2, 64, 64)), ("art", (1, 40, 136)),
                                         ("photo", (1, 8, 8)), ("art", (3, 8, 12))])
 def test_network_vs_oracle_ragged(mode, shape, precision):
@@ -474,7 +479,7 @@ def test_native_runner_matches_python_path(tmp_path):
     from vstnet_amd.export import export_state_dict
     if not os.path.exists(_lib.RUNNER_BIN):
         _lib.build_runner()
-    for mode, precision in (("photo", "f16x2"), ("art", "f16x2"), ("photo", "bf16x3")):
+    for mode, precision in (("photo", "f16x2h"), ("art", "f16x2h"), ("photo", "f16x2"), ("photo", "bf16x3")):
         net, sd, sp = make_net(mode, precision)
         hd = 16 if mode == "photo" else 64
         export_state_dict(sd, str(tmp_path / "w.bin"), hd, sp)
@@ -483,7 +488,7 @@ def test_native_runner_matches_python_path(tmp_path):
         s = torch.randint(0, 256, (1, 32, 48, 3), dtype=torch.uint8, generator=g)
         c.numpy().tofile(tmp_path / "c.rgb"); s.numpy().tofile(tmp_path / "s.rgb")
         r = subprocess.run([_lib.RUNNER_BIN, str(tmp_path / "w.bin"), str(tmp_path / "c.rgb"), "40", "64",
-                            str(tmp_path / "s.rgb"), "32", "48", str(tmp_path / "o.rgb")] + ([] if precision == "f16x2" else [precision]),
+                            str(tmp_path / "s.rgb"), "32", "48", str(tmp_path / "o.rgb")] + ([] if precision == "f16x2h" else [precision]),
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr + r.stdout
         got = np.fromfile(tmp_path / "o.rgb", dtype=np.uint8).reshape(40, 64, 3)
@@ -676,7 +681,7 @@ def _oracle_1024(mode):
     return _FULL[mode]
 
 
-@pytest.mark.parametrize("precision,tol", [("f16x2", 2e-4), ("bf16x3", TIGHT)])
+@pytest.mark.parametrize("precision,tol", [("f16x2h", 2.5e-4), ("f16x2", 2e-4), ("bf16x3", TIGHT)])
 @pytest.mark.parametrize("mode", ["photo", "art"])
 def test_full_size_1024_vs_oracle(mode, precision, tol):
     """BASELINE config 2 (photo) and a config-3 frame (art) at the full 1024x1024 against the oracle on the same inputs:
@@ -868,7 +873,7 @@ def test_transfer_with_stats_inplace():
         assert out.data_ptr() == zc.data_ptr() and torch.equal(out, ref) and not torch.equal(zc, keep)
 
 
-@pytest.mark.parametrize("precision", ["f16x2", "bf16x3", "fp32"])
+@pytest.mark.parametrize("precision", ["f16x2h", "f16x2", "bf16x3", "fp32"])
 def test_packed_code_equals_dense_path(precision):
     """net(x) in photorealistic mode returns a PackedCode (vstnet_amd/code.py): the code in the coupling blocks' own layout.
     It must be the same [B,32,H,W] tensor to every caller, and encode -> cWCT -> decode on the packed rows must give what the
@@ -918,7 +923,7 @@ def test_packed_code_equals_dense_path(precision):
         got = net(cw.transfer(net(x.cuda()), net(xs.cuda())), forward=False)
     zc, zs_ = cpu_ref.revnet_forward(x, sd, sp), cpu_ref.revnet_forward(xs, sd, sp)
     ref = cpu_ref.revnet_inverse(cpu_ref.transfer(zc, zs_), sd, sp)
-    assert_close(got, ref, 2e-4 if precision == "f16x2" else TIGHT, "stylised frame through the packed code vs oracle")
+    assert_close(got, ref, NET_TOL[precision], "stylised frame through the packed code vs oracle")
 
 
 @pytest.mark.parametrize("kind", ["bands", "noise"])
@@ -965,7 +970,7 @@ def test_packed_code_masked_transfer(kind):
         assert_close(out1 if not isinstance(out1, PackedCode) else out1.materialize(), out0, 1e-5, "11 labels", tol_max=1e-4)
 
 
-@pytest.mark.parametrize("precision", ["f16x2", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f16x2h", "f16x2", "bf16x3"])
 def test_packed_code_artistic(precision):
     """The artistic net's code [B,128,H/2,W/2] as a PackedCode: rows of 128 floats; statistics on ten 32 x 32 MFMA blocks,
     the affine map on the exact-fp32 MFMA inside the decode.  Against the dense route and the oracle."""
@@ -997,4 +1002,4 @@ def test_packed_code_artistic(precision):
         got = net(cw.transfer(net(x.cuda()), net(xs.cuda())), forward=False)
     zc, zs_ = cpu_ref.revnet_forward(x, sd, sp), cpu_ref.revnet_forward(xs, sd, sp)
     ref = cpu_ref.revnet_inverse(cpu_ref.transfer(zc, zs_), sd, sp)
-    assert_close(got, ref, 2e-4 if precision == "f16x2" else TIGHT, "artistic stylised frame through the packed code vs oracle")
+    assert_close(got, ref, NET_TOL[precision], "artistic stylised frame through the packed code vs oracle")

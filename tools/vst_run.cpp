@@ -34,14 +34,16 @@ static bool read_file(const char* path, std::vector<uint8_t>& buf) {
 
 int main(int argc, char** argv) {
     if (argc != 9 && argc != 10) {
-        fprintf(stderr, "usage: %s weights.bin content.rgb H W style.rgb Hs Ws out.rgb [f16x2|bf16x3|fp32]\n", argv[0]);
+        fprintf(stderr, "usage: %s weights.bin content.rgb H W style.rgb Hs Ws out.rgb [f16x2h|f16x2|bf16x3|fp32]\n", argv[0]);
         return 1;
     }
-    int prec = VST_PREC_F16X2;                    // the drop-in classes' default
+    int prec = VST_PREC_F16X2H;                   // the drop-in classes' default
     if (argc == 10) {
         if (!strcmp(argv[9], "bf16x3")) prec = VST_PREC_BF16X3;
         else if (!strcmp(argv[9], "fp32")) prec = VST_PREC_FP32;
-        else if (strcmp(argv[9], "f16x2")) { fprintf(stderr, "unknown precision %s\n", argv[9]); return 1; }
+        else if (!strcmp(argv[9], "f16x2h")) prec = VST_PREC_F16X2H;
+        else if (!strcmp(argv[9], "f16x2")) prec = VST_PREC_F16X2;
+        else { fprintf(stderr, "unknown precision %s\n", argv[9]); return 1; }
     }
     const int H = atoi(argv[3]), W = atoi(argv[4]), Hs = atoi(argv[6]), Ws = atoi(argv[7]);
     std::vector<uint8_t> wfile, content, style;

@@ -20,6 +20,7 @@ NUM_BLOCKS = 32
 PREC_BF16X3 = 0
 PREC_FP32 = 1
 PREC_F16X2 = 2
+PREC_F16X2H = 3
 
 # every symbol include/vstnet.h declares
 EXPORTS = [

@@ -69,6 +69,10 @@ __device__ __forceinline__ void split8_sp(const float (&f)[8], u32x4& hi, u32x4&
 __device__ __forceinline__ unsigned sp_offset(int cig, int plane, int y, int x, int H, int W) {
     return ((((unsigned)cig * 2 + plane) * H + y) * W + x) * 16u;
 }
+// the same for a tensor kept as ONE fp16 plane (VST_PREC_F16X2H: h2)
+__device__ __forceinline__ unsigned sp_offset1(int cig, int y, int x, int H, int W) {
+    return (((unsigned)cig * H + y) * W + x) * 16u;
+}
 #endif
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is per device: set it once per (kernel, device), not once per process
@@ -130,9 +134,11 @@ int vst3_block256(const vst_block_weights* w, int direction, int precision, floa
                   int pos, int src_planes_ready, int B, int H, int W, void* stream);
 // the stride-2 256-channel block's conv.4 (h1 planes -> h2 planes) and conv.7 (h2 planes -> fp32 state read-modify-write,
 // optionally also the new state's planes into planes A) on the same kernels; conv.1 is conv.hip's stride-2 kernel writing planes
-int vst3_conv_mid(const vst_conv_weights* c, const void* in_sp, void* out_sp, int B, int H, int W, void* stream);
-int vst3_conv_out(const vst_conv_weights* c, const void* in_sp, float* state, void* out_sp, float sign, int B, int H, int W,
-                  void* stream);
+// (out_single / in_single: h2 as one fp16 plane, VST_PREC_F16X2H)
+int vst3_conv_mid(const vst_conv_weights* c, const void* in_sp, void* out_sp, int out_single, int B, int H, int W, void* stream);
+int vst3_conv_out(const vst_conv_weights* c, const void* in_sp, int in_single, float* state, void* out_sp, float sign, int B,
+                  int H, int W, void* stream);
+static inline bool vst_is_f16(int precision) { return precision == VST_PREC_F16X2 || precision == VST_PREC_F16X2H; }
 
 // the split-plane buffer idx (0 = A, 1 = B) inside tmp; layout.hip: gather whose first half goes straight into split planes
 unsigned char* vst3_plane_buffer(void* tmp, int idx, int B, int H, int W);

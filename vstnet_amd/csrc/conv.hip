@@ -972,7 +972,7 @@ static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) 
         VST_RETURN_IF_LAUNCH_FAILED();
         return VST_OK;
     }
-    if (precision != VST_PREC_BF16X3 && precision != VST_PREC_F16X2) return VST_E_MODE;
+    if (precision != VST_PREC_BF16X3 && !vst_is_f16(precision)) return VST_E_MODE;
     vst_prof_scope prof(VST_KERNEL_ID(CIN, COUT, STRIDE), st);
     if constexpr (CIN >= 64 && COUT >= 64 && STRIDE == 1) {
         using C = PipeCfg<CIN, COUT>;
@@ -987,7 +987,7 @@ static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) 
         // f16x2: the convs of the 16- and 64-channel blocks run the 2-term fp16 product as well (one weight plane in LDS: one
         // more workgroup per CU, a third fewer MFMAs)
         constexpr bool T2_SHAPE = (CIN == 64 && COUT == 16) || (CIN == 16 && COUT == 16 && STRIDE == 2) || (CIN == 16 && COUT == 4);
-        const bool t2 = T2_SHAPE && precision == VST_PREC_F16X2;
+        const bool t2 = T2_SHAPE && vst_is_f16(precision);
         auto kern = t2 ? conv_mfma_kernel<CIN, COUT, STRIDE, IN_STATE, OUT_STATE, false, T2_SHAPE ? 2 : 3>
                        : conv_mfma_kernel<CIN, COUT, STRIDE, IN_STATE, OUT_STATE, false, 3>;
         const int lds = t2 ? C::LDS_BYTES_T2 : C::LDS_BYTES;
@@ -1026,7 +1026,7 @@ static int launch_conv_s2_planes(const ConvArgs& a, int B, hipStream_t st) {
 template <int MID, int CH>
 static int launch_pair(const ConvArgs& a, int B, int precision, hipStream_t st) {
     constexpr int T2 = 2;                                    // f16x2: the pair runs the 2-term fp16 product
-    const bool t2 = T2 == 2 && precision == VST_PREC_F16X2;
+    const bool t2 = T2 == 2 && vst_is_f16(precision);
     vst_prof_scope prof(VST_KERNEL_ID(MID, CH, 1), st);
     // (-DVST_PAIR_MR2=1: the 64-channel blocks' 2-term pair on 8 x 16 tiles - 33 KB of LDS, 96 VGPRs, four workgroups per CU,
     // eight per CU and launch at 1024 x 1024 in two even rounds instead of 3 + 1: 7 % faster alone, 0.6 % slower in the frame)
@@ -1062,7 +1062,7 @@ static int run_block(const vst_block_weights* w, int direction, int precision, f
     a.Hin = Ho * STRIDE; a.Win = Wo * STRIDE; a.Hout = Ho; a.Wout = Wo;
     a.in_img_stride = state_img; a.out_img_stride = mid_img; a.sign = 0.f;
     if constexpr (CH == 256 && STRIDE == 2) {
-        if (precision == VST_PREC_F16X2) {
+        if (vst_is_f16(precision)) {
             // the F16X2 path: h1 / h2 as split fp16 planes, conv.4 and conv.7 on conv3.hip's kernels.  In a forward pass the
             // new state half also goes out as planes: it is the src of the run of stride-1 blocks that follows.
             const size_t mid_bytes = (size_t)Ho * Wo * 64 * 4, state_bytes = (size_t)Ho * Wo * 256 * 4;
@@ -1073,9 +1073,11 @@ static int run_block(const vst_block_weights* w, int direction, int precision, f
             a.out_sp = h1p; a.out_sp_img_bytes = mid_bytes;
             int rc2 = launch_conv_s2_planes(a, B, st);
             if (rc2) return rc2;
-            rc2 = vst3_conv_mid(&w->conv[1], h1p, h2p, B, H, W, st);
+            const int h2_single = precision == VST_PREC_F16X2H;
+            rc2 = vst3_conv_mid(&w->conv[1], h1p, h2p, h2_single, B, H, W, st);
             if (rc2) return rc2;
-            return vst3_conv_out(&w->conv[2], h2p, dst, direction > 0 ? planes_a : nullptr, direction > 0 ? 1.f : -1.f, B, H, W, st);
+            return vst3_conv_out(&w->conv[2], h2p, h2_single, dst, direction > 0 ? planes_a : nullptr, direction > 0 ? 1.f : -1.f,
+                                 B, H, W, st);
         }
     }
     int rc = launch_conv<IN_CH, MID, STRIDE, true, false>(a, B, precision, st);
@@ -1182,7 +1184,7 @@ int vst_block_apply(const vst_block_weights* w, int channel, int stride, int dir
     if (channel == 64 && stride == 1) return run_block<64, 1>(w, direction, precision, dst, src, t, B, H, W, st);
     if (channel == 64 && stride == 2) return run_block<64, 2>(w, direction, precision, dst, src, t, B, H, W, st);
     if (channel == 256 && stride == 1) {
-        if (precision == VST_PREC_F16X2)
+        if (vst_is_f16(precision))
 #if defined(VST_SP_ABLATE) && (VST_SP_ABLATE & 8)
             return vst3_block256(w, direction, precision, dst, src, tmp, 5, 0, B, H, W, stream);   // diagnostic build: a mid-run block
 #else
@@ -1217,7 +1219,7 @@ static int forward_blocks(const vst_net_weights* w, const float* x, const uint8_
     if (rc) return rc;
     rc = vst_pack_input_k(x, x_u8, s[0], s[1], B, x_u8 ? 3 : C_in, H, W, fold0 ? k16 : nullptr, stream);
     if (rc) return rc;
-    const bool sp = precision == VST_PREC_F16X2;
+    const bool sp = vst_is_f16(precision);
     for (int k = fold0 ? 1 : 0; k < VST_NUM_BLOCKS; ++k) {
         if (sp && k >= 21)      // block k's conv.7 leaves the split planes of its dst = block k+1's src
             rc = vst3_block256(&w->blocks[k], +1, precision, s[k & 1], s[1 - (k & 1)], tmp, k - 21, 1, B, H, W, stream);
@@ -1244,7 +1246,7 @@ static int revnet_forward_chunk(const vst_net_weights* w, const float* x, const 
 // tmp - block 31 reads its src only through them and block 30 takes its old values from them too), output unpacking included
 static int inverse_blocks(const vst_net_weights* w, float* x, uint8_t* x_u8, float* const s[2], float* tmp, int B, int C_out,
                           int H, int W, int precision, void* stream) {
-    const bool sp = precision == VST_PREC_F16X2;
+    const bool sp = vst_is_f16(precision);
     int rc = VST_OK;
     for (int k = VST_NUM_BLOCKS - 1; k >= 0; --k) {
         if (sp && k >= 21)
@@ -1265,7 +1267,7 @@ static int revnet_inverse_chunk(const vst_net_weights* w, const float* z, float*
     s[1] = s[0] + (size_t)B * H * W * 16;
     float* tmp = s[1] + (size_t)B * H * W * 16;
     // f16x2: the gather writes s[0] straight into plane buffer 0 (no fp32 copy, no pre-split pass)
-    const bool sp = precision == VST_PREC_F16X2;
+    const bool sp = vst_is_f16(precision);
     const int rc = sp ? vst3_gather_planes(z, vst3_plane_buffer(tmp, 0, B, H, W), s[1], B, H, W, sp_steps, stream)
                       : vst_gather(z, s[0], s[1], B, H, W, sp_steps, stream);
     if (rc) return rc;
@@ -1301,7 +1303,7 @@ static int revnet_decode_labels_any(const vst_net_weights* w, const float* code,
     const size_t img = (size_t)32 * H * W;
     float* s[2] = {(float*)workspace, (float*)workspace + img / 2};
     float* tmp = (float*)workspace + img;
-    unsigned char* planes0 = precision == VST_PREC_F16X2 ? vst3_plane_buffer(tmp, 0, 1, H, W) : nullptr;
+    unsigned char* planes0 = vst_is_f16(precision) ? vst3_plane_buffer(tmp, 0, 1, H, W) : nullptr;
     int rc = vst3_apply_labels_code(code, s[0], s[1], planes0, H, W, affines, mask_rows, plan, max_slots, stream);
     if (rc) return rc;
     return inverse_blocks(w, x, x_u8, s, tmp, 1, C_out, H, W, precision, stream);
@@ -1317,7 +1319,7 @@ static int revnet_decode_any(const vst_net_weights* w, const float* code, const 
     const size_t img = (size_t)32 * H * W;
     float* s[2] = {(float*)workspace, (float*)workspace + img / 2};
     float* tmp = (float*)workspace + img;
-    const bool sp = precision == VST_PREC_F16X2;
+    const bool sp = vst_is_f16(precision);
     unsigned char* planes0 = sp ? vst3_plane_buffer(tmp, 0, 1, H, W) : nullptr;
     hipStream_t st = (hipStream_t)stream;
     for (int b = 0; b < B; ++b) {

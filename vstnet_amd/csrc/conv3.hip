@@ -52,14 +52,16 @@ __device__ __forceinline__ void glds16(const unsigned char* g, unsigned char* ld
 
 template <int N> __device__ __forceinline__ void sp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int CIN, int COUT>
+// IN1: the input tensor is ONE fp16 plane ([8-channel group][y][x][8 x fp16], the values rounded to fp16) instead of the hi / lo
+// pair: one MFMA per product (VST_PREC_F16X2H: h2, the input of the 256-channel blocks' conv.7)
+template <int CIN, int COUT, bool IN1 = false>
 struct SpCfg {
     static constexpr int NW = 8;                             // waves, each owning 2 tile rows x 16 pixels x 64 output channels
     static constexpr int NCHUNK = CIN / 32, NCOT = COUT / 64, Q = NCHUNK * NCOT;
     static constexpr int MR = 2, TH = NW * MR, IW = 18, NPIX = (TH + 2) * IW;
     static constexpr int NSLOT = (NPIX + 15) / 16 * 16;      // multiple of 16: the four k-group planes start 256 B apart mod the 256-B bank row
-    static constexpr int A_PLANE = 4 * NSLOT * 16, A_BUF = 2 * A_PLANE;      // [plane][cig][slot][16 B]
-    static constexpr int APIECES = A_BUF / 1024;             // DMA pieces (64 lanes x 16 B) per chunk image (42)
+    static constexpr int A_PLANE = 4 * NSLOT * 16, A_BUF = (IN1 ? 1 : 2) * A_PLANE;   // [plane][cig][slot][16 B]
+    static constexpr int APIECES = A_BUF / 1024;             // DMA pieces (64 lanes x 16 B) per chunk image (42, or 21)
     // Only waves 0-3 issue DMA ("loaders"); their SIMD partners 4-7 run nothing but fragment reads and MFMAs, so the matrix
     // pipe of every SIMD has a wave to draw from while the other one is busy issuing pieces.
     static constexpr int NLOAD = 4;
@@ -71,9 +73,10 @@ struct SpCfg {
     static_assert(APW <= 18 && WPW == 9, "one weight piece and at most two image pieces per k-step");
 };
 
-template <int CIN, int COUT, bool OUT_STATE>
+// OUT1 (kernels that write an intermediate, not the state): the output is written as one fp16 plane
+template <int CIN, int COUT, bool OUT_STATE, bool IN1 = false, bool OUT1 = false>
 __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
-    using C = SpCfg<CIN, COUT>;
+    using C = SpCfg<CIN, COUT, IN1>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const Abuf = smem;
     unsigned char* const Bbuf = smem + 2 * C::A_BUF;
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
 #define SP_STAMP()
 #endif
     const unsigned char* const in_img = a.in + (size_t)b * a.in_img_bytes;
-    const size_t chunk_bytes = (size_t)128 * H * W;           // 4 channel groups x 2 planes
+    const size_t chunk_bytes = (size_t)(IN1 ? 64 : 128) * H * W;   // 4 channel groups x 2 planes (or one)
 
     // ---- per-lane DMA source offsets ----------------------------------------------------------------------------
     // The activation image of one chunk (2 planes x 4 groups x NSLOT slots x 16 B) is APIECES pieces of 64 lanes, APW per
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
         slot = slot > C::NPIX - 1 ? C::NPIX - 1 : slot;
         const int iy = slot / C::IW, ix = slot - iy * C::IW;
         const int gy = reflect_clamp(ty0 - 1 + iy, H), gx = reflect_clamp(tx0 - 1 + ix, W);
-        a_off[u] = (unsigned)sp_offset(pc & 3, pc >> 2, gy, gx, H, W);
+        a_off[u] = IN1 ? (unsigned)sp_offset1(pc & 3, gy, gx, H, W) : (unsigned)sp_offset(pc & 3, pc >> 2, gy, gx, H, W);
         a_dst[u] = i * 1024;
     }
     const bool loader = wave < C::NLOAD;
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
 #pragma unroll
         for (int m = 0; m < C::MR; ++m) {
             f.xh[m] = *(const f16x8*)(Ab + ((m + dy) * C::IW + dx) * 16);
-            f.xl[m] = *(const f16x8*)(Ab + C::A_PLANE + ((m + dy) * C::IW + dx) * 16);
+            if (!IN1) f.xl[m] = *(const f16x8*)(Ab + C::A_PLANE + ((m + dy) * C::IW + dx) * 16);
         }
     };
 
@@ -194,8 +197,12 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
                 u32x4 hi_, lo_;                                                                                               \
                 split8_sp(f8_, hi_, lo_);                                                                                     \
                 const int cig_ = pend_cot * 8 + j_ * 4 + kg;                                                                  \
-                *(u32x4*)(sp_img + sp_offset(cig_, 0, oy_, ox, H, W)) = hi_;                                                  \
-                *(u32x4*)(sp_img + sp_offset(cig_, 1, oy_, ox, H, W)) = lo_;                                                  \
+                if (OUT1) {                                                                                                   \
+                    *(u32x4*)(sp_img + sp_offset1(cig_, oy_, ox, H, W)) = hi_;                                                \
+                } else {                                                                                                      \
+                    *(u32x4*)(sp_img + sp_offset(cig_, 0, oy_, ox, H, W)) = hi_;                                              \
+                    *(u32x4*)(sp_img + sp_offset(cig_, 1, oy_, ox, H, W)) = lo_;                                              \
+                }                                                                                                             \
             }                                                                                                                 \
         }                                                                                                                     \
     }
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
             if (!(VST_SP_ABLATE & 1) && loader) {
                 if (issue_w) ISSUE_W1(q + 1, k);
                 if (issue_a) {
-                    ISSUE_A1(q + 1, k);
+                    if (k < C::APW) ISSUE_A1(q + 1, k);       // (a one-plane image has 6 pieces per loader wave, fewer than k-steps)
                     if (9 + k < C::APW) ISSUE_A1(q + 1, 9 + k);
                 }
             }
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
             for (int m = 0; m < C::MR; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[n], f.xl[m], acc[m][n], 0, 0, 0);
+                    if (!IN1) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[n], f.xl[m], acc[m][n], 0, 0, 0);
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[n], f.xh[m], acc[m][n], 0, 0, 0);
                 }
             if (k == 2 || k == 5) SP_STAMP();
@@ -354,10 +361,10 @@ __global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__
     }
 }
 
-template <int CIN, int COUT, bool OUT_STATE>
+template <int CIN, int COUT, bool OUT_STATE, bool IN1 = false, bool OUT1 = false>
 static int launch_sp(SpArgs a, int B, hipStream_t st) {
-    using C = SpCfg<CIN, COUT>;
-    auto kern = conv_sp_kernel<CIN, COUT, OUT_STATE>;
+    using C = SpCfg<CIN, COUT, IN1>;
+    auto kern = conv_sp_kernel<CIN, COUT, OUT_STATE, IN1, OUT1>;
     static std::atomic<unsigned> attr_done{0};
     if (int rc = vst_ensure_dynamic_lds((const void*)kern, C::LDS_BYTES + ((VST_SP_ABLATE & 8) ? 512 : 0), &attr_done)) return rc;
     a.tiles_x = (a.W + 15) / 16; a.tiles_y = (a.H + C::TH - 1) / C::TH; a.tiles_total = a.tiles_x * a.tiles_y * B;
@@ -372,26 +379,28 @@ static const unsigned char* sp_frag(const vst_conv_weights& c, int cout, int cin
     return (const unsigned char*)c.packed + L.f32_bytes + 2 * L.frag_bytes;
 }
 
-int vst3_conv_mid(const vst_conv_weights* c, const void* in_sp, void* out_sp, int B, int H, int W, void* stream) {
+int vst3_conv_mid(const vst_conv_weights* c, const void* in_sp, void* out_sp, int out_single, int B, int H, int W, void* stream) {
     const int Hq = H >> 2, Wq = W >> 2;
     SpArgs a{};
     a.H = Hq; a.W = Wq;
     a.in = (const unsigned char*)in_sp; a.out_sp = (unsigned char*)out_sp;
-    a.in_img_bytes = a.out_img_bytes = (size_t)Hq * Wq * 64 * 4;
+    a.in_img_bytes = (size_t)Hq * Wq * 64 * 4;
+    a.out_img_bytes = (size_t)Hq * Wq * 64 * (out_single ? 2 : 4);
     a.wfrag = sp_frag(*c, 64, 64); a.bias = c->bias;
-    return launch_sp<64, 64, false>(a, B, (hipStream_t)stream);
+    return out_single ? launch_sp<64, 64, false, false, true>(a, B, (hipStream_t)stream)
+                      : launch_sp<64, 64, false>(a, B, (hipStream_t)stream);
 }
 
-int vst3_conv_out(const vst_conv_weights* c, const void* in_sp, float* state, void* out_sp, float sign, int B, int H, int W,
-                  void* stream) {
+int vst3_conv_out(const vst_conv_weights* c, const void* in_sp, int in_single, float* state, void* out_sp, float sign, int B,
+                  int H, int W, void* stream) {
     const int Hq = H >> 2, Wq = W >> 2;
     SpArgs a{};
     a.H = Hq; a.W = Wq; a.state_img_floats = (size_t)Hq * Wq * 256;
-    a.in = (const unsigned char*)in_sp; a.in_img_bytes = (size_t)Hq * Wq * 64 * 4;
+    a.in = (const unsigned char*)in_sp; a.in_img_bytes = (size_t)Hq * Wq * 64 * (in_single ? 2 : 4);
     a.state = state; a.old_sp = nullptr; a.store_f32 = 1;
     a.out_sp = (unsigned char*)out_sp; a.out_img_bytes = (size_t)Hq * Wq * 256 * 4;
     a.wfrag = sp_frag(*c, 256, 64); a.bias = c->bias; a.sign = sign;
-    return launch_sp<64, 256, true>(a, B, (hipStream_t)stream);
+    return in_single ? launch_sp<64, 256, true, true>(a, B, (hipStream_t)stream) : launch_sp<64, 256, true>(a, B, (hipStream_t)stream);
 }
 
 // fp32 half state [B][H/4][W/4][256] -> its split planes
@@ -415,7 +424,8 @@ unsigned char* vst3_plane_buffer(void* tmp, int idx, int B, int H, int W) {
 
 int vst3_block256(const vst_block_weights* w, int direction, int precision, float* dst, const float* src, void* tmp,
                   int pos, int src_planes_ready, int B, int H, int W, void* stream) {
-    if (precision != VST_PREC_F16X2) return VST_E_MODE;
+    if (!vst_is_f16(precision)) return VST_E_MODE;
+    const bool h2_single = precision == VST_PREC_F16X2H;    // h2 as one fp16 plane: conv.7 issues one MFMA per product
     hipStream_t st = (hipStream_t)stream;
     const int Hq = H >> 2, Wq = W >> 2;
     const size_t mid_bytes = (size_t)Hq * Wq * 64 * 4, state_bytes = (size_t)Hq * Wq * 256 * 4;
@@ -443,20 +453,20 @@ int vst3_block256(const vst_block_weights* w, int direction, int precision, floa
     int rc = launch_sp<256, 64, false>(a, B, st);
     if (rc) return rc;
     // conv.4: h1 -> h2
-    a.in = h1; a.in_img_bytes = mid_bytes; a.out_sp = h2;
+    a.in = h1; a.in_img_bytes = mid_bytes; a.out_sp = h2; a.out_img_bytes = h2_single ? mid_bytes / 2 : mid_bytes;
     a.wfrag = frag(w->conv[1], 64, 64); a.bias = w->conv[1].bias;
-    rc = launch_sp<64, 64, false>(a, B, st);
+    rc = h2_single ? launch_sp<64, 64, false, false, true>(a, B, st) : launch_sp<64, 64, false>(a, B, st);
     if (rc) return rc;
     // conv.7: h2 -> dst += sign * (.).  The old dst values: fp32 for the first block of a run, afterwards the planes of this
     // block's dst buffer (pos 1: block 0's src planes, from block 20 / the gather; later: what block pos-2 wrote; read before
     // written, same lane).  The new values go to
     // the planes (the next block's src / the block after's old values) except for the run's last block, and to the fp32 state
     // for the last writer of each half (pos >= 9) and for a block on its own.
-    a.in = h2; a.out_img_bytes = state_bytes; a.state = dst;
+    a.in = h2; a.in_img_bytes = h2_single ? mid_bytes / 2 : mid_bytes; a.out_img_bytes = state_bytes; a.state = dst;
     a.old_sp = (!alone && p >= 1) ? sp_dst : nullptr;
     a.store_f32 = alone || p >= 9;
     a.out_sp = (!alone && p < 10) ? sp_dst : nullptr;
     a.wfrag = frag(w->conv[2], 256, 64); a.bias = w->conv[2].bias;
     a.sign = direction > 0 ? 1.f : -1.f;
-    return launch_sp<64, 256, true>(a, B, st);
+    return h2_single ? launch_sp<64, 256, true, true>(a, B, st) : launch_sp<64, 256, true>(a, B, st);
 }

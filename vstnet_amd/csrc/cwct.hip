@@ -2085,7 +2085,7 @@ int vst_cwct_prefactor(const double* stats, int N, float eps, double* out, int* 
 int vst_cwct_apply_prec(const float* x, float* y, int N, long L, const float* affine, const uint8_t* mask, int label,
                         int precision, void* stream) {
     if (!x || !y || !affine || L <= 0) return VST_E_ARG;
-    if (precision != VST_PREC_BF16X3 && precision != VST_PREC_FP32 && precision != VST_PREC_F16X2) return VST_E_MODE;
+    if (precision != VST_PREC_BF16X3 && precision != VST_PREC_FP32 && !vst_is_f16(precision)) return VST_E_MODE;
     const bool exact = precision == VST_PREC_FP32;
     hipStream_t st = (hipStream_t)stream;
     vst_prof_scope prof(VST_KERNEL_CWCT_APPLY, st);
@@ -2170,7 +2170,7 @@ int vst_cwct_factor_labels(const double* content_stats, const double* style_stat
 int vst_cwct_apply_labels(const float* x, float* y, int N, long L, const float* affines, const uint8_t* mask, const void* plan,
                           int max_slots, int precision, void* stream) {
     if (!x || !y || !affines || !mask || !plan || L <= 0) return VST_E_ARG;
-    if (precision != VST_PREC_BF16X3 && precision != VST_PREC_FP32 && precision != VST_PREC_F16X2) return VST_E_MODE;
+    if (precision != VST_PREC_BF16X3 && precision != VST_PREC_FP32 && !vst_is_f16(precision)) return VST_E_MODE;
     if (max_slots <= 0 || max_slots > CWCT_MAX_SLOTS) max_slots = CWCT_MAX_SLOTS;
     hipStream_t st = (hipStream_t)stream;
     vst_prof_scope prof(VST_KERNEL_CWCT_APPLY, st);

@@ -53,9 +53,9 @@ class cWCT(nn.Module):
         # arithmetic of the apply (y = T x + t0): "fp32" = exact fp32 kernels for every N; anything else lets unmasked
         # N >= 64 codes (artistic mode) run on bf16 MFMA with split operands.  Follows RevResNet's knob by default.
         import os
-        precision = precision or os.environ.get("VST_PRECISION", "f16x2")
-        if precision not in ("fp32", "bf16x3", "f16x2"):
-            raise ValueError("precision must be one of ['bf16x3', 'f16x2', 'fp32']")
+        precision = precision or os.environ.get("VST_PRECISION", "f16x2h")
+        if precision not in ("fp32", "bf16x3", "f16x2", "f16x2h"):
+            raise ValueError("precision must be one of ['bf16x3', 'f16x2', 'f16x2h', 'fp32']")
         self.precision = precision
         if use_double:
             raise NotImplementedError("vstnet_amd.cWCT(use_double=True): the HIP path factors and applies in fp32 (statistics "
@@ -138,7 +138,7 @@ class cWCT(nn.Module):
         if out is None:
             out = torch.empty_like(x2d)
         with torch.cuda.device(x2d.device):
-            prec = {"fp32": _lib.PREC_FP32, "bf16x3": _lib.PREC_BF16X3, "f16x2": _lib.PREC_F16X2}[self.precision]
+            prec = {"fp32": _lib.PREC_FP32, "bf16x3": _lib.PREC_BF16X3, "f16x2": _lib.PREC_F16X2, "f16x2h": _lib.PREC_F16X2H}[self.precision]
             _lib.check(_lib.lib().vst_cwct_apply_prec(_ptr(x2d), _ptr(out), N, Lp, _ptr(affine), _ptr(mask), int(label),
                                                       prec, _stream_ptr()), "vst_cwct_apply_prec")
         return out
@@ -340,7 +340,7 @@ class cWCT(nn.Module):
             with torch.cuda.device(c.device):
                 _lib.check(L.vst_cwct_factor_labels(_ptr(cs), _ptr(ss), _ptr(tab), ms, float(self.eps), N, _ptr(affines),
                                                     _ptr(info), _stream_ptr()), "vst_cwct_factor_labels")
-                prec = {"fp32": _lib.PREC_FP32, "bf16x3": _lib.PREC_BF16X3, "f16x2": _lib.PREC_F16X2}[self.precision]
+                prec = {"fp32": _lib.PREC_FP32, "bf16x3": _lib.PREC_BF16X3, "f16x2": _lib.PREC_F16X2, "f16x2h": _lib.PREC_F16X2H}[self.precision]
                 _lib.check(L.vst_cwct_apply_labels(_ptr(c[b]), _ptr(out[b]), N, c.shape[2], _ptr(affines), _ptr(plan.cm[b]),
                                                    _ptr(tab), ms, prec, _stream_ptr()), "vst_cwct_apply_labels")
             self.last_info = info

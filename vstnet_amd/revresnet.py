@@ -19,7 +19,7 @@ from . import _lib
 from .code import PackedCode
 from .synth import STACK, CONV_IDX
 
-_PRECISIONS = {"bf16x3": _lib.PREC_BF16X3, "fp32": _lib.PREC_FP32, "f16x2": _lib.PREC_F16X2}
+_PRECISIONS = {"bf16x3": _lib.PREC_BF16X3, "fp32": _lib.PREC_FP32, "f16x2": _lib.PREC_F16X2, "f16x2h": _lib.PREC_F16X2H}
 
 
 def _stream_ptr() -> C.c_void_p:
@@ -78,7 +78,7 @@ class RevResNet(nn.Module):
         self.sp_steps = sp_steps
         self.stack = nn.ModuleList([residual_block(ch, stride, mult=mult, kernel=kernel) for stride, ch in STACK])
         self.channel_reduction = channel_reduction(nChannels[-1], hidden_dim, sp_steps=sp_steps, kernel=kernel)
-        precision = precision or os.environ.get("VST_PRECISION", "f16x2")
+        precision = precision or os.environ.get("VST_PRECISION", "f16x2h")
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
         self.precision = precision
