@@ -45,9 +45,10 @@ extern "C" {
                                operands are pre-split in HBM and staged by LDS-DMA:
                                ~1.5e-4 rel on the code, ~4e-6 on a stylised frame */
 
-#define VST_PREC_F16X2H 3   /* F16X2, except that the 64-channel intermediate h2 of the 256-channel blocks (the input of their
-                               last conv) is kept as ONE fp16 plane: that conv issues one MFMA per product and reads half the
-                               bytes: ~1.6e-4 rel (1.8e-4 max) on the code, ~2.5e-5 on a stylised frame */
+#define VST_PREC_F16X2H 3   /* F16X2 with two intermediates kept in fp16 (11 bits) instead of fp16 hi + lo: h2 of the 256-channel
+                               blocks (the input of their last conv: one MFMA per product, half the bytes) and h1 of the
+                               16- and 64-channel blocks (2 bytes per value through HBM instead of 4):
+                               ~1.6e-4 rel (1.8e-4 max) on the code, ~3e-5 on a stylised frame */
 
 #define VST_NUM_BLOCKS 32   /* 30 stack blocks + 2 channel_reduction blocks */
 

@@ -901,10 +901,12 @@ def test_packed_code_equals_dense_path(precision):
             t, td = cw.transfer(z, zs), cw.transfer(zd, zsd)
             assert isinstance(t, PackedCode) and t.pending_affines is not None
             assert_close(t.materialize(), td, 2e-5, f"transfer on packed rows {B}x{H}x{W}")
+            # (the two z_cs differ by ~1e-6; under f16x2h the rounded intermediates turn part of that into fp16 steps)
+            tol_out = 1e-4 if precision == "f16x2h" else 2e-5
             out, outd = net(t, forward=False), dense(td, forward=False)
-            assert float((out - outd).abs().max()) <= 2e-5
+            assert float((out - outd).abs().max()) <= tol_out
             # cached style statistics, a mix of two styles with a content share, and the uint8 edge
-            assert float((net(cw.transfer_with_stats(z, cw.style_stats(zs)), forward=False) - outd).abs().max()) <= 2e-5
+            assert float((net(cw.transfer_with_stats(z, cw.style_stats(zs)), forward=False) - outd).abs().max()) <= tol_out
             mix, mixd = cw.interpolation(z, [zs, z], [0.6, 0.4], 0.3), cw.interpolation(zd, [zsd, zd], [0.6, 0.4], 0.3)
             assert_close(mix.materialize(), mixd, 2e-5, "interpolation on packed rows")
             u8, u8d = net.inverse_u8(t), dense.inverse_u8(td)

@@ -226,7 +226,9 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, float* out_img, in
 #define VST_EARLY_OLD 1
 #endif
 // ---- generic kernel: one tile per workgroup, staging per input-channel chunk (all shapes) --------------
-template <int CIN, int COUT, int STRIDE, bool IN_STATE, bool OUT_STATE, bool OUT_SP = false, int TERMS = 3>
+// OUT_H16 (an intermediate h1, not the state): ReLU(acc + bias) is written as fp16, channels-last like the fp32 form
+// (VST_PREC_F16X2H: the pair kernel reads h1 as the fp16 operand it is, one MFMA per product in conv.4)
+template <int CIN, int COUT, int STRIDE, bool IN_STATE, bool OUT_STATE, bool OUT_SP = false, int TERMS = 3, bool OUT_H16 = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     using C = ConvCfg<CIN, COUT, STRIDE>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -414,6 +416,25 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         }
         return;
     }
+    if constexpr (OUT_H16) {
+        static_assert(!OUT_STATE && !OUT_SP, "fp16 output: the h1 intermediates only");
+        _Float16* const o16 = (_Float16*)a.out + (size_t)b * a.out_img_stride;
+#pragma unroll
+        for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+            for (int n = 0; n < C::NB; ++n) {
+                const int oy = ty0 + wave * C::MR + m, ox = tx0 + lrow, co = co0 + 4 * kg + n * 16;
+                if (oy >= a.Hout || ox >= a.Wout || co >= COUT) continue;
+                const float r[4] = {acc[m][n][0] + bias[n].x, acc[m][n][1] + bias[n].y, acc[m][n][2] + bias[n].z, acc[m][n][3] + bias[n].w};
+                typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+                f16x4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (_Float16)__builtin_amdgcn_fmed3f(r[e], 0.f, 65504.f);     // ReLU, saturating
+                *(f16x4*)(o16 + ((size_t)oy * a.Wout + ox) * COUT + co) = h;
+            }
+        VST_TRACE_END(2)
+        return;
+    }
     if (OUT_STATE && !EARLY_OLD) fetch_old();
     if (interior) store_tile<COUT, OUT_STATE, C::MR, C::NB, true>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, acc, bias, old);
     else store_tile<COUT, OUT_STATE, C::MR, C::NB>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, acc, bias, old);
@@ -425,7 +446,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 // (18x18 positions, from a 20x20 region of h1) into the LDS image that conv.7's MFMAs read, then does
 // dst += sign * (conv.7(h2) + bias).  ReflectionPad of h2 (RevResNet.py:85): an in-image pixel one step inside the
 // border also writes the mirrored ring slot.  LDS: [h2 image][ union { h1 region + conv.4 weights ; conv.7 weights } ].
-template <int CIN>
+template <int CIN, bool NO_LO = false>
 __device__ __forceinline__ void read_x_small(const unsigned char* img_hi, const unsigned char* img_lo, int nslot,
                                              int slot00, int iw, int ks, int kg, bf16x8& xh, bf16x8& xl) {
     if (CIN == 16) {
@@ -434,20 +455,24 @@ __device__ __forceinline__ void read_x_small(const unsigned char* img_hi, const 
         const int slot = slot00 + (tap / 3) * iw + tap % 3;
         const int aoff = ((kg & 1) * nslot + slot) * 16;
         xh = __builtin_bit_cast(bf16x8, *(const uint4*)(img_hi + aoff));
-        xl = __builtin_bit_cast(bf16x8, *(const uint4*)(img_lo + aoff));
+        if (!NO_LO) xl = __builtin_bit_cast(bf16x8, *(const uint4*)(img_lo + aoff)); else xl = xh;
     } else {
         int t0 = 8 * ks + 2 * kg;
         t0 = t0 > 8 ? 8 : t0;
         const int t1 = t0 + 1 > 8 ? 8 : t0 + 1;
         const int s0 = slot00 + (t0 / 3) * iw + t0 % 3, s1 = slot00 + (t1 / 3) * iw + t1 % 3;
         const uint2 h0 = *(const uint2*)(img_hi + s0 * 8), h1 = *(const uint2*)(img_hi + s1 * 8);
-        const uint2 l0 = *(const uint2*)(img_lo + s0 * 8), l1 = *(const uint2*)(img_lo + s1 * 8);
         xh = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
-        xl = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+        if (!NO_LO) {
+            const uint2 l0 = *(const uint2*)(img_lo + s0 * 8), l1 = *(const uint2*)(img_lo + s1 * 8);
+            xl = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+        } else {
+            xl = xh;
+        }
     }
 }
 
-template <int MID, int CH, int TERMS = 3, int MR = 4>
+template <int MID, int CH, int TERMS = 3, int MR = 4, bool H16 = false>
 struct PairCfg {
     using C7 = ConvCfg<MID, CH, 1, MR>;
     // h1 region (TH + 4 rows x 20 columns), h2 ring region (TH + 2 rows x 18 columns) of a TH x 16 tile, TH = 4 MR
@@ -458,14 +483,17 @@ struct PairCfg {
     // workgroups per CU); MID == 4: everything is small, conv.7's weights get their own region (one barrier fewer)
     static constexpr bool ALIAS = MID == 16;
     static constexpr int WPL = TERMS == 3 ? 2 : 1;            // weight planes in LDS (hi + lo, or the fp16 plane alone)
-    static constexpr int H1W4 = 2 * H1_PLANE + WPL * W4_PLANE;
+    static constexpr int H1W4 = (H16 ? 1 : 2) * H1_PLANE + WPL * W4_PLANE;   // H16: h1 arrives as fp16, one plane
     static constexpr int U_BYTES = ALIAS ? (H1W4 > WPL * C7::B_PLANE ? H1W4 : WPL * C7::B_PLANE) : H1W4 + WPL * C7::B_PLANE;
     static constexpr int LDS_BYTES = 2 * C7::A_PLANE + U_BYTES;
 };
 
-template <int MID, int CH, int TERMS = 3, int MR = 4>
+// H16: h1 is fp16 in HBM (conv_mfma_kernel<..., OUT_H16>): it is copied into the LDS image as it is and conv.4 issues one
+// MFMA per product
+template <int MID, int CH, int TERMS = 3, int MR = 4, bool H16 = false>
 __global__ __launch_bounds__(256, (MID == 16 && TERMS == 2) ? 3 : 1) void conv_pair_kernel(const ConvArgs a) {
-    using P = PairCfg<MID, CH, TERMS, MR>;
+    static_assert(!H16 || TERMS == 2, "fp16 h1: the 2-term kernels only");
+    using P = PairCfg<MID, CH, TERMS, MR, H16>;
     using C = typename P::C7;
     static_assert(C::NCHUNK == 1 && C::NCOT == 1, "single-chunk shapes");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -475,8 +503,8 @@ __global__ __launch_bounds__(256, (MID == 16 && TERMS == 2) ? 3 : 1) void conv_p
     unsigned char* const b_hi = P::ALIAS ? u0 : u0 + P::H1W4;   // conv.7 weights (aliased: valid after conv.4 is done)
     unsigned char* const b_lo = TERMS == 3 ? b_hi + C::B_PLANE : b_hi;
     unsigned char* const h1_hi = u0;                         // h1 region + conv.4 weights (before)
-    unsigned char* const h1_lo = u0 + P::H1_PLANE;
-    unsigned char* const w4s_hi = u0 + 2 * P::H1_PLANE;
+    unsigned char* const h1_lo = H16 ? u0 : u0 + P::H1_PLANE;           // (H16: no lo plane)
+    unsigned char* const w4s_hi = u0 + (H16 ? 1 : 2) * P::H1_PLANE;
     unsigned char* const w4s_lo = TERMS == 3 ? w4s_hi + P::W4_PLANE : w4s_hi;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -499,6 +527,7 @@ __global__ __launch_bounds__(256, (MID == 16 && TERMS == 2) ? 3 : 1) void conv_p
     constexpr int W4_ITEMS = C::KS * 4 * 16, W4IT = (W4_ITEMS + 255) / 256;
     constexpr int W7_ITEMS = C::KS * 4 * C::NT, W7IT = (W7_ITEMS + 255) / 256;
     f32x4 hreg[H1IT][NV];
+    u32x4 h16reg[H16 ? H1IT : 1];                            // (H16: raw fp16 words - never routed through float registers)
     u32x4 w4reg[W4IT][2], w7reg[W7IT][2];
     // ---- fetch everything this workgroup reads, back to back ---------------------------------------------------------
 #pragma unroll
@@ -515,9 +544,15 @@ __global__ __launch_bounds__(256, (MID == 16 && TERMS == 2) ? 3 : 1) void conv_p
         const int cig = MID == 4 ? 0 : idx % C::CIG, slot = MID == 4 ? idx : idx / C::CIG;
         const int iy = slot / P::R1, ix = slot - iy * P::R1;
         const int gy = reflect_clamp(ty0 - 2 + iy, H), gx = reflect_clamp(tx0 - 2 + ix, W);
-        const float* p = in_img + ((size_t)gy * W + gx) * MID + cig * 8;
-        hreg[it][0] = *(const f32x4*)p;
-        if (NV == 2) hreg[it][NV - 1] = *(const f32x4*)(p + 4);
+        if constexpr (H16) {                                   // 8 (MID == 16) or 4 (MID == 4) fp16 values: the operand itself
+            const _Float16* p16 = (const _Float16*)a.in + (size_t)b * a.in_img_stride + ((size_t)gy * W + gx) * MID + cig * 8;
+            if (MID == 4) { const uint2 v = *(const uint2*)p16; h16reg[it] = u32x4{v.x, v.y, 0u, 0u}; }
+            else h16reg[it] = *(const u32x4*)p16;
+        } else {
+            const float* p = in_img + ((size_t)gy * W + gx) * MID + cig * 8;
+            hreg[it][0] = *(const f32x4*)p;
+            if (NV == 2) hreg[it][NV - 1] = *(const f32x4*)(p + 4);
+        }
     }
 #pragma unroll
     for (int it = 0; it < W7IT; ++it) {
@@ -542,7 +577,14 @@ __global__ __launch_bounds__(256, (MID == 16 && TERMS == 2) ? 3 : 1) void conv_p
     for (int it = 0; it < H1IT; ++it) {
         int idx = it * 256 + tid;
         idx = idx < H1_ITEMS ? idx : H1_ITEMS - 1;
-        if (MID == 4) {
+        if constexpr (H16) {
+            if (MID == 4) {
+                *(uint2*)(h1_hi + idx * 8) = make_uint2(h16reg[it][0], h16reg[it][1]);
+            } else {
+                const int cig = idx % C::CIG, slot = idx / C::CIG;
+                *(u32x4*)(h1_hi + (cig * P::N1SLOT + slot) * 16) = h16reg[it];
+            }
+        } else if (MID == 4) {
             uint2 h, l;
             SPLIT4_T(F4(hreg[it][0]), h, l);
             *(uint2*)(h1_hi + idx * 8) = h;
@@ -614,8 +656,12 @@ __global__ __launch_bounds__(256, (MID == 16 && TERMS == 2) ? 3 : 1) void conv_p
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     bf16x8 xh, xl;
-                    read_x_small<MID>(h1_hi, h1_lo, P::N1SLOT, ryv[u] * P::R1 + rxv[u], P::R1, ks, kg, xh, xl);
-                    MFMA_T(acc4[u], wh, wl, xh, xl);
+                    read_x_small<MID, H16>(h1_hi, h1_lo, P::N1SLOT, ryv[u] * P::R1 + rxv[u], P::R1, ks, kg, xh, xl);
+                    if constexpr (H16) {
+                        acc4[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh), __builtin_bit_cast(f16x8, xh), acc4[u], 0, 0, 0);
+                    } else {
+                        MFMA_T(acc4[u], wh, wl, xh, xl);
+                    }
                 }
             }
 #pragma unroll
@@ -963,7 +1009,7 @@ void vst_prof_close(int rec, hipStream_t st) {
 }
 
 template <int CIN, int COUT, int STRIDE, bool IN_STATE, bool OUT_STATE>
-static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) {
+static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st, bool out_h16 = false) {
     if (precision == VST_PREC_FP32) {
         const size_t total = (size_t)B * a.Hout * a.Wout * COUT;
         size_t blocks = (total + 255) / 256;
@@ -988,11 +1034,14 @@ static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st) 
         // more workgroup per CU, a third fewer MFMAs)
         constexpr bool T2_SHAPE = (CIN == 64 && COUT == 16) || (CIN == 16 && COUT == 16 && STRIDE == 2) || (CIN == 16 && COUT == 4);
         const bool t2 = T2_SHAPE && vst_is_f16(precision);
-        auto kern = t2 ? conv_mfma_kernel<CIN, COUT, STRIDE, IN_STATE, OUT_STATE, false, T2_SHAPE ? 2 : 3>
+        constexpr bool H16_SHAPE = T2_SHAPE && !OUT_STATE;      // an h1 intermediate of a 16- / 64-channel block
+        const bool h16 = t2 && out_h16 && H16_SHAPE;
+        auto kern = h16 ? conv_mfma_kernel<CIN, COUT, STRIDE, IN_STATE, OUT_STATE, false, T2_SHAPE ? 2 : 3, H16_SHAPE>
+                  : t2 ? conv_mfma_kernel<CIN, COUT, STRIDE, IN_STATE, OUT_STATE, false, T2_SHAPE ? 2 : 3>
                        : conv_mfma_kernel<CIN, COUT, STRIDE, IN_STATE, OUT_STATE, false, 3>;
         const int lds = t2 ? C::LDS_BYTES_T2 : C::LDS_BYTES;
-        static std::atomic<unsigned> attr_done[2];
-        if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, lds, &attr_done[t2 ? 1 : 0])) return rc_;
+        static std::atomic<unsigned> attr_done[3];
+        if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, lds, &attr_done[h16 ? 2 : (t2 ? 1 : 0)])) return rc_;
         ConvArgs t = a;
         t.tiles_x = (a.Wout + C::TW - 1) / C::TW; t.tiles_y = (a.Hout + C::TH - 1) / C::TH;
         t.tiles_total = t.tiles_x * t.tiles_y * B * C::NCOT;
@@ -1027,6 +1076,18 @@ template <int MID, int CH>
 static int launch_pair(const ConvArgs& a, int B, int precision, hipStream_t st) {
     constexpr int T2 = 2;                                    // f16x2: the pair runs the 2-term fp16 product
     const bool t2 = T2 == 2 && vst_is_f16(precision);
+    if (precision == VST_PREC_F16X2H) {                      // h1 arrives as fp16 (launch_conv(..., out_h16 = true) wrote it)
+        using P = PairCfg<MID, CH, 2, 4, true>;
+        vst_prof_scope prof(VST_KERNEL_ID(MID, CH, 1), st);
+        auto kern = conv_pair_kernel<MID, CH, 2, 4, true>;
+        static std::atomic<unsigned> attr_h16{0};
+        if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, P::LDS_BYTES, &attr_h16)) return rc_;
+        ConvArgs t = a;
+        t.tiles_x = (a.Wout + 15) / 16; t.tiles_y = (a.Hout + 15) / 16; t.tiles_total = t.tiles_x * t.tiles_y * B;
+        kern<<<dim3((t.tiles_total + 7) / 8 * 8), 256, P::LDS_BYTES, st>>>(t);
+        VST_RETURN_IF_LAUNCH_FAILED();
+        return VST_OK;
+    }
     vst_prof_scope prof(VST_KERNEL_ID(MID, CH, 1), st);
     // (-DVST_PAIR_MR2=1: the 64-channel blocks' 2-term pair on 8 x 16 tiles - 33 KB of LDS, 96 VGPRs, four workgroups per CU,
     // eight per CU and launch at 1024 x 1024 in two even rounds instead of 3 + 1: 7 % faster alone, 0.6 % slower in the frame)
@@ -1080,7 +1141,9 @@ static int run_block(const vst_block_weights* w, int direction, int precision, f
                                  B, H, W, st);
         }
     }
-    int rc = launch_conv<IN_CH, MID, STRIDE, true, false>(a, B, precision, st);
+    // f16x2h: h1 of the 16- / 64-channel blocks goes through HBM as fp16 (the pair kernel that reads it is chosen by the same test)
+    const bool h16 = CH <= 64 && VST_PAIR && precision == VST_PREC_F16X2H;
+    int rc = launch_conv<IN_CH, MID, STRIDE, true, false>(a, B, precision, st, h16);
     if (rc) return rc;
     if constexpr (CH <= 64 && VST_PAIR) {
         if (precision != VST_PREC_FP32) {         // conv.4 + conv.7 in one launch, h2 stays in LDS
