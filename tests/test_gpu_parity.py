@@ -130,9 +130,10 @@ def test_block_golden(L, golden, name, k, channel, stride, precision, tol):
 # f16x2: weights rounded to fp16 once (measured 1.44e-4 rel-L2 / 1.51e-4 max-rel on the 1024x1024 code); f16x2h: in addition the
 # 64-channel input of the 256-channel blocks' last conv rounded to fp16 (1.54e-4 / 1.80e-4).  Both far inside the 1e-3 budget.
 NET_TOL = {"fp32": 5e-6, "bf16x3": TIGHT, "f16x2": 2e-4, "f16x2h": 2.5e-4}
-# inverse(forward(x)): the same deterministic F in both directions; f16x2h's rounding of an intermediate makes F a step function
-# of its input, so the fp32 rounding of the recovered states is amplified a little (measured 1.3e-5 max-rel)
-RT_TOL = {"fp32": 5e-6, "bf16x3": 5e-6, "f16x2": 5e-6, "f16x2h": 3e-5}
+# inverse(forward(x)): the same deterministic F in both directions; f16x2h's fp16 intermediates / conv inputs make F a step
+# function of its input, so the fp32 rounding of the recovered states is amplified (measured up to 4.2e-5 max-rel, i.e. 1 % of an
+# 8-bit level)
+RT_TOL = {"fp32": 5e-6, "bf16x3": 5e-6, "f16x2": 5e-6, "f16x2h": 1e-4}
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x2", "f16x2h"])

@@ -73,9 +73,12 @@ struct SpCfg {
     static_assert(APW <= 18 && WPW == 9, "one weight piece and at most two image pieces per k-step");
 };
 
+// INL: 0 = the input is a hi / lo pair (two MFMAs per product); 1 = a one-plane tensor; 2 = the HI plane of a hi / lo pair (the
+// state planes as conv.1 of a 256-channel block reads them under VST_PREC_F16X2H).  1 and 2: one MFMA per product.
 // OUT1 (kernels that write an intermediate, not the state): the output is written as one fp16 plane
-template <int CIN, int COUT, bool OUT_STATE, bool IN1 = false, bool OUT1 = false>
+template <int CIN, int COUT, bool OUT_STATE, int INL = 0, bool OUT1 = false>
 __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
+    constexpr bool IN1 = INL != 0;
     using C = SpCfg<CIN, COUT, IN1>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const Abuf = smem;
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
 #define SP_STAMP()
 #endif
     const unsigned char* const in_img = a.in + (size_t)b * a.in_img_bytes;
-    const size_t chunk_bytes = (size_t)(IN1 ? 64 : 128) * H * W;   // 4 channel groups x 2 planes (or one)
+    const size_t chunk_bytes = (size_t)(INL == 1 ? 64 : 128) * H * W;   // 4 channel groups x 2 planes (or one) in HBM
 
     // ---- per-lane DMA source offsets ----------------------------------------------------------------------------
     // The activation image of one chunk (2 planes x 4 groups x NSLOT slots x 16 B) is APIECES pieces of 64 lanes, APW per
@@ -119,7 +122,8 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
         slot = slot > C::NPIX - 1 ? C::NPIX - 1 : slot;
         const int iy = slot / C::IW, ix = slot - iy * C::IW;
         const int gy = reflect_clamp(ty0 - 1 + iy, H), gx = reflect_clamp(tx0 - 1 + ix, W);
-        a_off[u] = IN1 ? (unsigned)sp_offset1(pc & 3, gy, gx, H, W) : (unsigned)sp_offset(pc & 3, pc >> 2, gy, gx, H, W);
+        a_off[u] = INL == 1 ? (unsigned)sp_offset1(pc & 3, gy, gx, H, W)
+                            : (unsigned)sp_offset(pc & 3, INL == 2 ? 0 : pc >> 2, gy, gx, H, W);
         a_dst[u] = i * 1024;
     }
     const bool loader = wave < C::NLOAD;
@@ -361,10 +365,10 @@ __global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__
     }
 }
 
-template <int CIN, int COUT, bool OUT_STATE, bool IN1 = false, bool OUT1 = false>
+template <int CIN, int COUT, bool OUT_STATE, int INL = 0, bool OUT1 = false>
 static int launch_sp(SpArgs a, int B, hipStream_t st) {
-    using C = SpCfg<CIN, COUT, IN1>;
-    auto kern = conv_sp_kernel<CIN, COUT, OUT_STATE, IN1, OUT1>;
+    using C = SpCfg<CIN, COUT, INL != 0>;
+    auto kern = conv_sp_kernel<CIN, COUT, OUT_STATE, INL, OUT1>;
     static std::atomic<unsigned> attr_done{0};
     if (int rc = vst_ensure_dynamic_lds((const void*)kern, C::LDS_BYTES + ((VST_SP_ABLATE & 8) ? 512 : 0), &attr_done)) return rc;
     a.tiles_x = (a.W + 15) / 16; a.tiles_y = (a.H + C::TH - 1) / C::TH; a.tiles_total = a.tiles_x * a.tiles_y * B;
@@ -387,7 +391,7 @@ int vst3_conv_mid(const vst_conv_weights* c, const void* in_sp, void* out_sp, in
     a.in_img_bytes = (size_t)Hq * Wq * 64 * 4;
     a.out_img_bytes = (size_t)Hq * Wq * 64 * (out_single ? 2 : 4);
     a.wfrag = sp_frag(*c, 64, 64); a.bias = c->bias;
-    return out_single ? launch_sp<64, 64, false, false, true>(a, B, (hipStream_t)stream)
+    return out_single ? launch_sp<64, 64, false, 0, true>(a, B, (hipStream_t)stream)
                       : launch_sp<64, 64, false>(a, B, (hipStream_t)stream);
 }
 
@@ -400,7 +404,7 @@ int vst3_conv_out(const vst_conv_weights* c, const void* in_sp, int in_single, f
     a.state = state; a.old_sp = nullptr; a.store_f32 = 1;
     a.out_sp = (unsigned char*)out_sp; a.out_img_bytes = (size_t)Hq * Wq * 256 * 4;
     a.wfrag = sp_frag(*c, 256, 64); a.bias = c->bias; a.sign = sign;
-    return in_single ? launch_sp<64, 256, true, true>(a, B, (hipStream_t)stream) : launch_sp<64, 256, true>(a, B, (hipStream_t)stream);
+    return in_single ? launch_sp<64, 256, true, 1>(a, B, (hipStream_t)stream) : launch_sp<64, 256, true>(a, B, (hipStream_t)stream);
 }
 
 // fp32 half state [B][H/4][W/4][256] -> its split planes
@@ -450,12 +454,13 @@ int vst3_block256(const vst_block_weights* w, int direction, int precision, floa
     // conv.1: planes(src) -> h1
     a.in = sp_src; a.in_img_bytes = state_bytes; a.out_sp = h1; a.out_img_bytes = mid_bytes; a.state = nullptr;
     a.wfrag = frag(w->conv[0], 64, 256); a.bias = w->conv[0].bias; a.sign = 0.f;
-    int rc = launch_sp<256, 64, false>(a, B, st);
+    // f16x2h: conv.1 reads only the hi plane of the state (one MFMA per product, half the image bytes; the state itself keeps both)
+    int rc = h2_single ? launch_sp<256, 64, false, 2>(a, B, st) : launch_sp<256, 64, false>(a, B, st);
     if (rc) return rc;
     // conv.4: h1 -> h2
     a.in = h1; a.in_img_bytes = mid_bytes; a.out_sp = h2; a.out_img_bytes = h2_single ? mid_bytes / 2 : mid_bytes;
     a.wfrag = frag(w->conv[1], 64, 64); a.bias = w->conv[1].bias;
-    rc = h2_single ? launch_sp<64, 64, false, false, true>(a, B, st) : launch_sp<64, 64, false>(a, B, st);
+    rc = h2_single ? launch_sp<64, 64, false, 0, true>(a, B, st) : launch_sp<64, 64, false>(a, B, st);
     if (rc) return rc;
     // conv.7: h2 -> dst += sign * (.).  The old dst values: fp32 for the first block of a run, afterwards the planes of this
     // block's dst buffer (pos 1: block 0's src planes, from block 20 / the gather; later: what block pos-2 wrote; read before
@@ -468,5 +473,5 @@ int vst3_block256(const vst_block_weights* w, int direction, int precision, floa
     a.out_sp = (!alone && p < 10) ? sp_dst : nullptr;
     a.wfrag = frag(w->conv[2], 256, 64); a.bias = w->conv[2].bias;
     a.sign = direction > 0 ? 1.f : -1.f;
-    return h2_single ? launch_sp<64, 256, true, true>(a, B, st) : launch_sp<64, 256, true>(a, B, st);
+    return h2_single ? launch_sp<64, 256, true, 1>(a, B, st) : launch_sp<64, 256, true>(a, B, st);
 }
