@@ -45,11 +45,11 @@ extern "C" {
                                operands are pre-split in HBM and staged by LDS-DMA:
                                ~1.5e-4 rel on the code, ~4e-6 on a stylised frame */
 
-#define VST_PREC_F16X2H 3   /* F16X2 with three conv inputs taken as fp16 (11 bits) instead of fp16 hi + lo: in the 256-channel
-                               blocks h2 (the input of the last conv) and the state as the first conv reads it (its hi
-                               plane; the state itself keeps hi + lo) - one MFMA per product, half the bytes -, and h1 of
-                               the 16- and 64-channel blocks (2 bytes per value through HBM instead of 4):
-                               ~1.7e-4 rel (1.8e-4 max) on the code, ~3.5e-5 (1e-4 max) on a stylised frame */
+#define VST_PREC_F16X2H 3   /* F16X2 with every conv input that crosses HBM taken as fp16 (11 bits) instead of fp16 hi + lo:
+                               in the 256-channel blocks h1, h2 and the state as the first conv reads it (its hi plane;
+                               the state itself keeps hi + lo) - one MFMA per product, half the bytes -, and h1 of the
+                               16- and 64-channel blocks (2 bytes per value through HBM instead of 4):
+                               ~1.75e-4 rel (1.94e-4 max) on the code, ~4e-5 (1.1e-4 max) on a stylised frame */
 
 #define VST_NUM_BLOCKS 32   /* 30 stack blocks + 2 channel_reduction blocks */
 

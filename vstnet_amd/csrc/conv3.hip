@@ -455,12 +455,13 @@ int vst3_block256(const vst_block_weights* w, int direction, int precision, floa
     a.in = sp_src; a.in_img_bytes = state_bytes; a.out_sp = h1; a.out_img_bytes = mid_bytes; a.state = nullptr;
     a.wfrag = frag(w->conv[0], 64, 256); a.bias = w->conv[0].bias; a.sign = 0.f;
     // f16x2h: conv.1 reads only the hi plane of the state (one MFMA per product, half the image bytes; the state itself keeps both)
-    int rc = h2_single ? launch_sp<256, 64, false, 2>(a, B, st) : launch_sp<256, 64, false>(a, B, st);
+    if (h2_single) a.out_img_bytes = mid_bytes / 2;         // (h1 as one fp16 plane too)
+    int rc = h2_single ? launch_sp<256, 64, false, 2, true>(a, B, st) : launch_sp<256, 64, false>(a, B, st);
     if (rc) return rc;
     // conv.4: h1 -> h2
-    a.in = h1; a.in_img_bytes = mid_bytes; a.out_sp = h2; a.out_img_bytes = h2_single ? mid_bytes / 2 : mid_bytes;
+    a.in = h1; a.in_img_bytes = h2_single ? mid_bytes / 2 : mid_bytes; a.out_sp = h2; a.out_img_bytes = h2_single ? mid_bytes / 2 : mid_bytes;
     a.wfrag = frag(w->conv[1], 64, 64); a.bias = w->conv[1].bias;
-    rc = h2_single ? launch_sp<64, 64, false, 0, true>(a, B, st) : launch_sp<64, 64, false>(a, B, st);
+    rc = h2_single ? launch_sp<64, 64, false, 1, true>(a, B, st) : launch_sp<64, 64, false>(a, B, st);
     if (rc) return rc;
     // conv.7: h2 -> dst += sign * (.).  The old dst values: fp32 for the first block of a run, afterwards the planes of this
     // block's dst buffer (pos 1: block 0's src planes, from block 20 / the gather; later: what block pos-2 wrote; read before
