@@ -25,6 +25,9 @@
 #include <atomic>
 #include "common.h"
 
+#ifndef VST_SP_BURST
+#define VST_SP_BURST 1
+#endif
 #ifndef VST_SP_ABLATE
 #define VST_SP_ABLATE 0      // timing-only builds: 1 = no DMA in the main loop, 2 = no MFMAs, 4 = no fragment re-reads,
                              // 16 = no deferred stores (the whole conv.7 epilogue is then dead code), 32 = no old-state loads
@@ -251,12 +254,23 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
         const unsigned char* Bb = Bbuf + (q & 1) * C::B_BUF + (kg * 64 + lrow) * 16;
         Frags fr[2];
         read_frags(fr[0], Ab, Bb, 0);
+        // One-term kernels (INL != 0): a stage's MFMAs (2.3 K cycles) are shorter than the DMA latency, so a piece issued at
+        // the stage's last k-step is waited for in full; the next stage's pieces all go out HERE, at the stage's top (their
+        // buffers were released by the barrier that ended stage q-1), and have the whole stage to land.
+        constexpr bool BURST = VST_SP_BURST && IN1;
+        if (BURST && !(VST_SP_ABLATE & 1) && loader) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                if (issue_w) ISSUE_W1(q + 1, k);
+                if (issue_a && k < C::APW) ISSUE_A1(q + 1, k);
+            }
+        }
         // ---- 9 k-steps; fragments double-buffered in registers; one DMA piece of each kind per k-step ----------------------
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             __builtin_amdgcn_sched_barrier(0);
             if (k < 8 && !(VST_SP_ABLATE & 4)) read_frags(fr[(k + 1) & 1], Ab, Bb, k + 1);
-            if (!(VST_SP_ABLATE & 1) && loader) {
+            if (!BURST && !(VST_SP_ABLATE & 1) && loader) {
                 if (issue_w) ISSUE_W1(q + 1, k);
                 if (issue_a) {
                     if (k < C::APW) ISSUE_A1(q + 1, k);       // (a one-plane image has 6 pieces per loader wave, fewer than k-steps)
