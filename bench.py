@@ -236,8 +236,9 @@ def main():
     per_rank_fps = [round(fpg * args.steps / t, 3) for t in per_rank_s]
 
     prec_note = {"f16x2": "f32 state / f32 accumulate; fp16 2-term split MFMA: w_hi (x_hi + x_lo)",
-                 "f16x2h": "f32 state / f32 accumulate; fp16 2-term split MFMA: w_hi (x_hi + x_lo); the 64-channel input of the "
-                           "256-channel blocks' last conv as one fp16 plane (1 MFMA per product there)",
+                 "f16x2h": "f32 state (fp16 hi+lo planes in the 256-channel blocks) / f32 accumulate; fp16 MFMA, weights rounded to "
+                           "fp16; conv inputs that cross HBM (h1, h2, the state as the 256-channel blocks' first conv reads it) are "
+                           "fp16 tensors: 1 MFMA per product; operands split in-kernel from the f32 state: fp16 hi+lo, 2 MFMAs",
                  "bf16x3": "f32 state / f32 accumulate; bf16 3-term split MFMA", "fp32": "f32"}[args.precision]
     rec = {
         "metric": "stylized frames/sec at 1024x1024 (1/2/4/8 GPU) + % HBM roofline",
@@ -282,8 +283,8 @@ def main():
 
 def conv_terms(f16, cin, cout, stride):
     """MFMA products issued per algorithmic product: 2 (fp16 2-term) in the f16x2 modes - 1 in the 256-channel blocks' last conv
-    under f16x2h, whose input is one fp16 plane -, 3 (bf16 3-term) in the bf16x3 mode."""
-    if f16 == "h" and (cin, cout, stride) == (64, 256, 1):
+    under f16x2h, whose inputs are fp16 planes -, 3 (bf16 3-term) in the bf16x3 mode."""
+    if f16 == "h" and cin >= 64 and cout >= 64 and stride == 1:
         return 1
     return 2 if f16 else 3
 
@@ -317,8 +318,9 @@ def roofline_from_table(table, n_frames, fpg, H, W, args, _lib):
         traffic = hit[0]["hbm_bytes_per_launch"] if hit else None
     # Both roofs of the launch; the binding one (the larger minimum time) is reported as `bound` / `achieved` / `frac`.
     per_px = CONV_BYTES[(cin, cout, stride)]
-    if f16 == "h" and (cin, cout, stride) in ((64, 64, 1), (64, 256, 1)):
-        per_px -= 128                                      # h2 is written / read as one fp16 plane: 128 instead of 256 B per pixel
+    if f16 == "h":                                         # fp16 tensors where f16x2 moves hi + lo pairs (or fp32)
+        per_px -= {(256, 64, 1): 512 + 128, (64, 64, 1): 128 + 128, (64, 256, 1): 128,      # state hi plane, h1, h2 of the 256-channel blocks
+                   (16, 4, 1): 8, (4, 16, 1): 8, (64, 16, 1): 32, (16, 64, 1): 32, (16, 16, 2): 32}.get((cin, cout, stride), 0)
     nbytes = per_px * px / div
     tbps = nbytes / (avg_ms * 1e-3) / 1e12
     t_hbm, t_mfma = nbytes / (HBM_PEAK_GBS * 1e9), flops / (MFMA_16BIT_PEAK_TFLOPS * 1e12)
