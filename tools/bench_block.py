@@ -28,7 +28,7 @@ def main():
     L = _lib.lib()
     H = W = args.size
     dev = torch.device("cuda", 0)
-    modes = {"bf16x3": _lib.PREC_BF16X3, "f16x2": _lib.PREC_F16X2}
+    modes = {"bf16x3": _lib.PREC_BF16X3, "f16x2": _lib.PREC_F16X2, "f16x2h": _lib.PREC_F16X2H}
     net = RevResNet().to(dev).eval()
     net.load_state_dict(synthetic_state_dict())
     w = net._ensure_packed(dev)
