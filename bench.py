@@ -221,6 +221,25 @@ def main():
                 "value": round(fpg * n3 / t3, 3), "unit": "frames/s", "per": "GPU", "passes": 3,
                 "note": "style re-encoded and re-factored for every frame (the reference's video loop, video_transfer.py:195): "
                         "3 RevResNet passes + style statistics per frame"}
+        if rank == 0 and world == 1 and not args.no_extras and not args.masked and args.precision == "f16x2h":
+            # the same frame in the two stricter arithmetic modes (every conv input at 22 bits / bf16 3-term), same streams
+            others = {}
+            for p_alt in ("f16x2", "bf16x3"):
+                net_a = RevResNet(hidden_dim=hd, sp_steps=sp, precision=p_alt)
+                net_a.load_state_dict(sd)
+                net_a = net_a.to(dev).eval()
+                s_alt = cw.style_stats(net_a(style))
+
+                def step_alt():
+                    st = streams[counter[0] % len(streams)]
+                    counter[0] += 1
+                    with torch.cuda.stream(st):
+                        return net_a(cw.transfer_with_stats(net_a(content, forward=True), s_alt), forward=False)
+                n_alt = max(2, min(args.steps, 60))
+                t_alt = timed_steps(step_alt, n_alt, 3, torch.cuda.synchronize, 1)
+                others[p_alt] = round(fpg * n_alt / t_alt, 3)
+                del net_a
+            extras["other_precisions_frames_per_s"] = others
         gpu_out = {}
         if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.masked:
             stylize_batch(recompute=False, keep=gpu_out)
