@@ -98,12 +98,12 @@ def run_block(L, net, k, channel, stride, direction, precision, dst_nchw, src_nc
     return zc_to_nchw(dst.cpu(), dst_nchw.shape[1])
 
 
-# F16X2 rounds the 256-channel blocks' weights to fp16 (2^-12): ~1e-4 per block on these fixtures; its budget here is 3e-4
-@pytest.mark.parametrize("precision,tol", [(_lib.PREC_FP32, 2e-6), (_lib.PREC_BF16X3, 2e-5), (_lib.PREC_F16X2, 3e-4)])
+# F16X2 rounds every block's weights to fp16 (2^-12): ~1e-4 of F per block on these fixtures; F16X2H also takes the conv inputs
+# that cross HBM as fp16.  Budgets here: 3e-4 / 4e-4 of the block's output.
+@pytest.mark.parametrize("precision,tol", [(_lib.PREC_FP32, 2e-6), (_lib.PREC_BF16X3, 2e-5), (_lib.PREC_F16X2, 3e-4),
+                                           (_lib.PREC_F16X2H, 4e-4)])
 @pytest.mark.parametrize("name,k,channel,stride", BLOCKS)
 def test_block_golden(L, golden, name, k, channel, stride, precision, tol):
-    if precision == _lib.PREC_F16X2 and channel != 256:
-        pytest.skip("only the 256-channel blocks differ from bf16x3 in this mode")
     g = golden("blocks")
     net, sd, _ = make_net("photo")
     x1, x2 = T(g[f"{name}_x1"]), T(g[f"{name}_x2"])
