@@ -28,6 +28,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_16BIT_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak
+PMC_FILE = "r03_pmc_hbm_traffic.json"   # committed rocprofv3 --pmc summary that `roofline.traffic` is read from (never measured live)
 
 # conv kernel classes by profile id (cin, cout, stride) -> (stage, output-pixel divisor w.r.t. the full-resolution frame,
 # multiply-accumulates per output pixel and launch); the (4,16) and (16,64) ids are the fused conv.4 + conv.7 launches
@@ -58,7 +59,9 @@ def parse_args(argv=None):
                     "per-pixel random labels (the worst case for any per-label tile skipping)")
     ap.add_argument("--mode", default="photo", choices=["photo", "art"])
     ap.add_argument("--frames-per-gpu", type=int, default=1)
-    ap.add_argument("--precision", default="f16x2h", choices=["f16x2", "f16x2h", "bf16x3", "fp32"])
+    ap.add_argument("--precision", default=None, choices=["f16x2", "f16x2h", "bf16x3", "fp32"],
+                    help="conv arithmetic of the timed region (`value`); default: the library's default = bf16x3, the fp32-class "
+                         "mode.  The fp16 modes are opt-in and reported per mode under `modes` with their own parity figures")
     ap.add_argument("--recompute-style", action="store_true", help="re-encode + re-factor the style every frame "
                     "(the reference's video loop, video_transfer.py:195) instead of caching it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -75,30 +78,15 @@ def parse_args(argv=None):
 
 
 def launch_ranks(n, argv):
-    """Start one child per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment) and wait for all of
-    them.  The parent never initialises a GPU; a failed rank takes the others down and its exit code is returned."""
+    """Start one child per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* and a CPU thread cap of cores // n in its
+    environment) and wait for all of them.  The parent never initialises a GPU; a failed rank takes the others down and its
+    exit code is returned."""
+    from vstnet_amd.sharding import launch_children, rank_environment
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
-    rc = 0
-    pending = list(procs)
-    while pending:
-        for p in list(pending):
-            code = p.poll()
-            if code is None:
-                continue
-            pending.remove(p)
-            if code != 0 and rc == 0:
-                rc = code
-                for other in pending:      # exactly the children started above
-                    other.terminate()
-        time.sleep(0.05)
-    return rc
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    return launch_children([cmd] * n, [rank_environment(r, n, port) for r in range(n)])
 
 
 def main():
@@ -120,11 +108,14 @@ def main():
     from models.cWCT import cWCT
     from vstnet_amd import _lib
     from vstnet_amd.synth import synthetic_state_dict, synthetic_frames
+    args.precision = args.precision or _lib.default_precision()
     n_dev = torch.cuda.device_count()          # counting devices does not initialise HIP
     use_nccl = world <= n_dev                 # fewer GPUs than ranks (rehearsal on a 1-GPU box): ranks share GPUs, gloo
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank % n_dev)
+        from vstnet_amd.sharding import rank_threads
+        torch.set_num_threads(rank_threads(world))        # the ranks of a node share its cores (launch_ranks caps OMP too)
         if use_nccl:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -141,7 +132,7 @@ def main():
     net = RevResNet(hidden_dim=hd, sp_steps=sp, precision=args.precision)
     net.load_state_dict(sd)
     net = net.to(dev).eval()
-    cw = cWCT()
+    cw = cWCT(precision=args.precision)
 
     # frame f of the job has seed (0, f); rank r owns a contiguous shard of the world*fpg frames
     first, last = shard_range(world * fpg, rank, world)
@@ -221,30 +212,55 @@ def main():
                 "value": round(fpg * n3 / t3, 3), "unit": "frames/s", "per": "GPU", "passes": 3,
                 "note": "style re-encoded and re-factored for every frame (the reference's video loop, video_transfer.py:195): "
                         "3 RevResNet passes + style statistics per frame"}
-        if rank == 0 and world == 1 and not args.no_extras and not args.masked and args.precision == "f16x2h":
-            # the same frame in the two stricter arithmetic modes (every conv input at 22 bits / bf16 3-term), same streams
-            others = {}
-            for p_alt in ("f16x2", "bf16x3"):
-                net_a = RevResNet(hidden_dim=hd, sp_steps=sp, precision=p_alt)
-                net_a.load_state_dict(sd)
-                net_a = net_a.to(dev).eval()
-                s_alt = cw.style_stats(net_a(style))
+        # ---- per arithmetic mode: rate, sequential rate, frame roofline and (below, against the CPU leg's oracle frame) parity --
+        mode_rates, mode_out = {}, {}
+        if rank == 0 and world == 1 and not args.no_extras and not args.masked and not args.recompute_style:
+            n_alt = max(2, min(args.steps, 60))
+            for p_alt in ("bf16x3", "f16x2", "f16x2h"):
+                if p_alt == args.precision:
+                    net_a, s_alt = net, s_stats
+                else:
+                    net_a = RevResNet(hidden_dim=hd, sp_steps=sp, precision=p_alt)
+                    net_a.load_state_dict(sd)
+                    net_a = net_a.to(dev).eval()
+                    s_alt = cw.style_stats(net_a(style))
+
+                def frame_alt(keep=None):
+                    z_c = net_a(content, forward=True)
+                    z_cs = cw.transfer_with_stats(z_c, s_alt)
+                    out = net_a(z_cs, forward=False)
+                    if keep is not None:
+                        keep.update(z_c=z_c, z_cs=z_cs, stylized=out)
+                    return out
 
                 def step_alt():
                     st = streams[counter[0] % len(streams)]
                     counter[0] += 1
                     with torch.cuda.stream(st):
-                        return net_a(cw.transfer_with_stats(net_a(content, forward=True), s_alt), forward=False)
-                n_alt = max(2, min(args.steps, 60))
+                        return frame_alt()
+
+                def step_seq():
+                    with torch.cuda.stream(streams[0]):
+                        return frame_alt()
                 t_alt = timed_steps(step_alt, n_alt, 3, torch.cuda.synchronize, 1)
-                others[p_alt] = round(fpg * n_alt / t_alt, 3)
-                del net_a
-            extras["other_precisions_frames_per_s"] = others
+                t_seq = timed_steps(step_seq, n_alt, 2, torch.cuda.synchronize, 1)
+                mode_rates[p_alt] = (fpg * n_alt / t_alt, fpg * n_alt / t_seq)
+                if not args.no_cpu_baseline:
+                    keep = {}
+                    frame_alt(keep)
+                    torch.cuda.synchronize()
+                    mode_out[p_alt] = {k: v[:1].float().cpu() for k, v in keep.items()}
+                if net_a is not net:
+                    del net_a
         gpu_out = {}
         if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.masked:
-            stylize_batch(recompute=False, keep=gpu_out)
-            torch.cuda.synchronize()
-            gpu_out = {k: v[:1].float().cpu() for k, v in gpu_out.items()}
+            if args.precision in mode_out:
+                gpu_out = mode_out[args.precision]
+            else:
+                stylize_batch(recompute=False, keep=gpu_out)
+                torch.cuda.synchronize()
+                gpu_out = {k: v[:1].float().cpu() for k, v in gpu_out.items()}
+        range_flags = _lib.range_flags(reset=False) if rank == 0 else 0
 
     frames_total = world * fpg * args.steps
     ms_per_step = elapsed / args.steps * 1e3
@@ -254,11 +270,12 @@ def main():
     frame_gbs = frame_bytes * fpg * args.steps / elapsed / 1e9     # per GPU
     per_rank_fps = [round(fpg * args.steps / t, 3) for t in per_rank_s]
 
-    prec_note = {"f16x2": "f32 state / f32 accumulate; fp16 2-term split MFMA: w_hi (x_hi + x_lo)",
+    prec_note = {"f16x2": "f32 state / f32 accumulate; fp16 2-term split MFMA: w_hi (x_hi + x_lo), weights rounded to fp16 (opt-in mode)",
                  "f16x2h": "f32 state (fp16 hi+lo planes in the 256-channel blocks) / f32 accumulate; fp16 MFMA, weights rounded to "
                            "fp16; conv inputs that cross HBM (h1, h2, the state as the 256-channel blocks' first conv reads it) are "
-                           "fp16 tensors: 1 MFMA per product; operands split in-kernel from the f32 state: fp16 hi+lo, 2 MFMAs",
-                 "bf16x3": "f32 state / f32 accumulate; bf16 3-term split MFMA", "fp32": "f32"}[args.precision]
+                           "fp16 tensors: 1 MFMA per product; operands split in-kernel from the f32 state: fp16 hi+lo, 2 MFMAs (opt-in mode)",
+                 "bf16x3": "f32 state / f32 accumulate; bf16 3-term split MFMA (a_hi w_hi + a_lo w_hi + a_hi w_lo): fp32-class, "
+                           "3e-6 of the reference; the library default", "fp32": "f32"}[args.precision]
     rec = {
         "metric": "stylized frames/sec at 1024x1024 (1/2/4/8 GPU) + % HBM roofline",
         "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -276,6 +293,21 @@ def main():
     if rank == 0 and table:
         rec["roofline"], rec["stages"] = roofline_from_table(table, n_prof, fpg, Hf, Wf, args, _lib)
     rec.update(extras)
+    if rank == 0:
+        rec["fp16_range_flags"] = {"value": int(range_flags), "note": "device-side flags since process start (vstnet.h VST_RANGE_*: "
+                                   "1 = an activation saturated at +-65504 in an fp16 mode, 2 = a weight beyond fp16); 0 = none"}
+        rec["timed_region_note"] = ("every step re-encodes the same content tensor: the working set of a frame (288 B/px of "
+                                    "workspace + code = 0.4 GB at 1024x1024, x frames in flight) is far beyond the 256 MiB "
+                                    "Infinity Cache, so HBM traffic per step equals a fresh frame's")
+    if mode_rates:
+        per_frame_bytes = (2 * 6540 + 384) * Hf * Wf
+        rec["modes"] = {m: {"frames_per_s": round(v[0], 3), "sequential_frames_per_s": round(v[1], 3),
+                            "frame_hbm_roofline_frac": round(per_frame_bytes * v[0] / 1e9 / HBM_PEAK_GBS, 4)}
+                        for m, v in mode_rates.items()}
+        rec["modes"]["note"] = ("same workload, same streams, per arithmetic mode; sequential = one HIP stream, one frame at a time; "
+                                "parity_* (added by the CPU leg) = this run's frame 0 vs the oracle frame; `value` is the mode "
+                                f"named in config.precision ({args.precision})")
+        rec["sequential_frames_per_s"] = rec["modes"].get(args.precision, {}).get("sequential_frames_per_s")
 
     if args.host_pipeline > 0 and not args.masked and fpg == 1:
         # PCIe-inclusive: uint8 frames in pageable host memory -> pinned ring -> H2D -> encode/cWCT/decode -> D2H -> host
@@ -293,7 +325,7 @@ def main():
                                 "frames": args.host_pipeline, "note": "uint8 HWC frames from and to host memory, pinned "
                                 "ring buffers, H2D/compute/D2H overlapped; PCIe-inclusive, not `value`"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        rec["cpu_baseline"] = cpu_baseline(sd, sp, Hf, Wf, gpu_out)
+        rec["cpu_baseline"] = cpu_baseline(sd, sp, Hf, Wf, gpu_out, mode_out=mode_out, modes_rec=rec.get("modes"))
     if rank == 0:
         print(json.dumps(rec), flush=True)
     if world > 1:
@@ -329,12 +361,19 @@ def roofline_from_table(table, n_frames, fpg, H, W, args, _lib):
         kname = f"conv_sp_kernel<{cin},{cout}> (fp16 {terms}-term, LDS-DMA)"
     else:
         kname = f"conv kernel <{cin},{cout},s{stride}> ({'fp16 2-term' if terms == 2 else 'bf16 3-term'})"
-    traffic = None
-    pmc_path = os.path.join(REPO, "profiles", "r02_pmc_hbm_traffic.json")
-    if os.path.exists(pmc_path) and (H, W) == (1024, 1024) and fpg == 1 and args.mode == "photo" and f16:
-        k = json.load(open(pmc_path))["kernels"]
-        hit = [v for n, v in k.items() if f"<{cin}, {cout}," in n and "conv_sp" in n]
-        traffic = hit[0]["hbm_bytes_per_launch"] if hit else None
+    # `traffic` is NOT measured in this run: rocprofv3 PMC counters need their own passes (separate --pmc runs); it is read from
+    # the committed summary of such a run of this same command, and `traffic_source` says which file, for which precision, from
+    # which commit — a kernel edited since then makes it stale, which the commit hash shows.
+    traffic, traffic_source = None, None
+    pmc_path = os.path.join(REPO, "profiles", PMC_FILE)
+    if os.path.exists(pmc_path) and (H, W) == (1024, 1024) and fpg == 1 and args.mode == "photo":
+        pmc = json.load(open(pmc_path))
+        if pmc.get("precision", "f16x2h") == args.precision:
+            names = [f"<{cin}, {cout},", f"<{cin},{cout},"]
+            hit = [v for n, v in pmc["kernels"].items() if any(t in n for t in names) and ("conv_sp" in n or "conv_pipe" in n or "conv_mfma" in n)]
+            traffic = hit[0]["hbm_bytes_per_launch"] if hit else None
+            traffic_source = {"file": "profiles/" + PMC_FILE, "precision": pmc.get("precision", "f16x2h"),
+                              "git_commit": pmc.get("git_commit"), "collected": "rocprofv3 --pmc, separate passes (not this run)"}
     # Both roofs of the launch; the binding one (the larger minimum time) is reported as `bound` / `achieved` / `frac`.
     per_px = CONV_BYTES[(cin, cout, stride)]
     if f16 == "h":                                         # fp16 tensors where f16x2 moves hi + lo pairs (or fp32)
@@ -347,7 +386,7 @@ def roofline_from_table(table, n_frames, fpg, H, W, args, _lib):
             "mfma": {"algorithmic_flops": int(flops), "achieved_TFLOPps": round(achieved, 2),
                      "frac": round(achieved / MFMA_16BIT_PEAK_TFLOPS, 4), "issued_frac": round(achieved * terms / MFMA_16BIT_PEAK_TFLOPS, 4)}}
     roof = {"kernel": kname + " — the conv class with the largest total time per frame",
-            "traffic": traffic, "avg_launch_ms": round(avg_ms, 5), "launches_per_frame": round(cnt, 1), "ms_per_frame": round(ms, 4),
+            "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": round(avg_ms, 5), "launches_per_frame": round(cnt, 1), "ms_per_frame": round(ms, 4),
             "both_roofs": both,
             "note": "the roof with the larger minimum time for the launch's ALGORITHMIC bytes / fp32 conv flops (2*9*cin*cout per output "
                     f"pixel) binds; the split issues {terms}x the algorithmic flops on the MFMA pipe (issued_frac); HIP events on the "
@@ -435,7 +474,16 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(sd, sp, H, W, gpu_out=None, timed_frames=3):
+def _parity(gpu, ref):
+    par = {}
+    for name, r in zip(("z_c", "z_cs", "stylized"), ref):
+        g = gpu[name].double()
+        r = r.double()
+        par[name] = {"rel_l2": float(((g - r).norm() / r.norm())), "max_rel": float(((g - r).abs().max() / r.abs().max()))}
+    return par
+
+
+def cpu_baseline(sd, sp, H, W, gpu_out=None, timed_frames=3, mode_out=None, modes_rec=None):
     """The oracle (CPU restatement of the reference's torch-op sequence) timed on this host's cores: one warm-up frame, then
     `timed_frames` frames of the same workload (style code precomputed, like the GPU leg).  The warm-up frame is the GPU
     leg's frame 0, so its code / transferred code / stylised frame are also the parity check of the GPU outputs."""
@@ -464,12 +512,14 @@ def cpu_baseline(sd, sp, H, W, gpu_out=None, timed_frames=3):
            "cpu_model": cpu_model(), "host_cores_visible": os.cpu_count(), "kind": "port",
            "sample": f"1 warm-up + {timed_frames} timed frames {W}x{H} (forward + cWCT + inverse, style code precomputed), "
                      "oracle/cpu_ref.py on torch CPU ops", "seconds_per_frame": [round(t, 2) for t in times]}
+    for m, out in (mode_out or {}).items():           # every arithmetic mode's frame 0 against the same oracle frame
+        if modes_rec is not None and m in modes_rec:
+            par = _parity(out, ref)
+            modes_rec[m]["parity_rel_l2"] = float(f"{max(v['rel_l2'] for v in par.values()):.3e}")
+            modes_rec[m]["parity_max_rel"] = float(f"{max(v['max_rel'] for v in par.values()):.3e}")
+            modes_rec[m]["parity_stylized_rel_l2"] = float(f"{par['stylized']['rel_l2']:.3e}")
     if gpu_out:
-        par = {}
-        for name, r in zip(("z_c", "z_cs", "stylized"), ref):
-            g = gpu_out[name].double()
-            r = r.double()
-            par[name] = {"rel_l2": float(((g - r).norm() / r.norm())), "max_rel": float(((g - r).abs().max() / r.abs().max()))}
+        par = _parity(gpu_out, ref)
         rec["parity_rel_l2"] = max(v["rel_l2"] for v in par.values())
         rec["parity_max_rel"] = max(v["max_rel"] for v in par.values())
         rec["parity"] = {k: {a: float(f"{b:.3e}") for a, b in v.items()} for k, v in par.items()}

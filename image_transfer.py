@@ -31,12 +31,13 @@ def build_parser():
     p.add_argument('--style_seg', type=str, default=None)
     p.add_argument('--auto_seg', action='store_true', default=False)
     p.add_argument('--synthetic_weights', action='store_true', default=False)
+    p.add_argument('--precision', type=str, default=None, help="conv arithmetic (default: the library's, bf16x3)")
     # the delldu fork's post-process (project/image_style/vstnet.py:189-220): keep the content's Lab luminance
     p.add_argument('--preserve_luminance', action='store_true', default=False)
     return p
 
 
-def build_network(mode, ckpoint, synthetic, device):
+def build_network(mode, ckpoint, synthetic, device, precision=None):
     from models.RevResNet import RevResNet
     if mode.lower() == "photorealistic":
         hd, sp = 16, 2
@@ -44,7 +45,7 @@ def build_network(mode, ckpoint, synthetic, device):
         hd, sp = 64, 1
     else:
         raise NotImplementedError()
-    net = RevResNet(hidden_dim=hd, sp_steps=sp)
+    net = RevResNet(hidden_dim=hd, sp_steps=sp, precision=precision)
     if synthetic:
         from vstnet_amd.synth import synthetic_state_dict
         net.load_state_dict(synthetic_state_dict(1234, hd, sp))
@@ -79,9 +80,9 @@ def main(argv=None):
         raise NotImplementedError("--auto_seg needs mmseg/SegFormer (not part of this repository); pass --content_seg/--style_seg")
     device = torch.device("cuda")
     os.makedirs(args.out_dir, exist_ok=True)
-    net = build_network(args.mode, args.ckpoint, args.synthetic_weights, device)
+    net = build_network(args.mode, args.ckpoint, args.synthetic_weights, device, args.precision)
     from models.cWCT import cWCT
-    cwct = cWCT()
+    cwct = cWCT(precision=args.precision)
 
     content = Image.open(args.content).convert('RGB')
     style = Image.open(args.style).convert('RGB')

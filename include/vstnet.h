@@ -30,6 +30,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with hidden default visibility for its host code: exactly the declarations below are exported */
+#pragma GCC visibility push(default)
 
 #define VST_OK 0
 #define VST_E_ARG (-1)      /* null pointer, non-positive size */
@@ -64,6 +66,24 @@ const char* vst_error_string(int code);
  * ------------------------------------------------------------------------------------------- */
 size_t vst_conv_packed_bytes(int cout, int cin);
 int vst_pack_conv(const float* w_oihw, int cout, int cin, void* packed, void* stream);
+
+/* Exponent normalisation of one residual_block's intermediates (models/RevResNet.py:79-88): ReLU is positively homogeneous, so
+ *   h1 = ReLU(W1 x + b1), h2 = ReLU(W4 h1 + b4), F = W7 h2 + b7
+ * is unchanged by (W1, b1) *= s1 per output channel, W4 /= s1 per input channel, (W4, b4) *= s2 per output channel, W7 /= s2 per
+ * input channel.  With s = 2^-round(log2 ||row||_2) (powers of two: exact in fp32, bit-identical results in the fp32-class
+ * modes) every intermediate channel's weight row has unit scale, so h1 / h2 have the scale of the state whatever per-channel
+ * scales a checkpoint was trained into, which is what the fp16 operand range of VST_PREC_F16X2 / F16X2H wants.  In place on
+ * DEVICE copies of the five tensors (OIHW fp32 / [cout]); call before vst_pack_conv.  scales (optional) = float[2 * c_mid]
+ * {s1, s2}.  c_mid <= 64. */
+int vst_normalize_block(float* w1, float* b1, float* w4, float* b4, float* w7, int c_in1, int c_mid, int c_out,
+                        float* scales, void* stream);
+
+/* fp16 range flags of the narrowed modes, accumulated on the device since the last reset: */
+#define VST_RANGE_SATURATED 1u /* an activation beyond +-65504 was clamped when it was rounded to fp16 (F16X2 / F16X2H) */
+#define VST_RANGE_WEIGHT 2u    /* vst_pack_conv met a weight beyond +-65504 (its fp16 copy is +-Inf; BF16X3 / FP32 unaffected) */
+/* *flags_host = OR of the flags raised on the current device; reset != 0 clears them.  Synchronises the device (a calibration
+ * / diagnostic call: RevResNet.check_range, bench.py, tests), never called by the passes themselves. */
+int vst_range_flags(unsigned* flags_host, int reset);
 
 typedef struct vst_conv_weights {
     const void* packed;   /* from vst_pack_conv */
@@ -241,6 +261,22 @@ int vst_cwct_apply_labels(const float* x, float* y, int N, long L, const float* 
  * vst_cwct_factor.  `out` may alias `stats`; info = int[1] retry count. */
 int vst_cwct_prefactor(const double* stats, int N, float eps, double* out, int* info, void* stream);
 
+/* ---- fp64 cWCT: cWCT(use_double=True), models/cWCT.py:13-16,35-47,66,106,220,238,259 -------------------------------------
+ * The reference converts the features to double and runs mean / covariance / Cholesky (with the same jitter schedule) / inverse
+ * / both products in fp64, then converts back.  Same records as the fp32 calls (stats = double[1 + N + N*N], info as in
+ * vst_cwct_factor) but: true fp64 two-pass statistics, an fp64 factorisation, affine = DOUBLE[N*N + N], and the apply
+ * accumulates in fp64 (y = float(T double(x) + t0); y may alias x; with a mask only matching pixels are written).
+ * A fidelity option, not a hot path (no script of the reference sets it): NCHW codes only, N in {16, 32, 64, 128}. */
+size_t vst_cwct_stats_f64_workspace_bytes(int N, long L);
+int vst_cwct_stats_f64(const float* x, int N, long L, const uint8_t* mask, int label, double* stats, void* workspace,
+                       void* stream);
+size_t vst_cwct_factor_f64_workspace_bytes(int N);
+int vst_cwct_factor_f64(const double* content_stats, const double* const* style_stats_host_array, const float* alphas_host,
+                        int n_styles, float alpha_c, float eps, int N, double* affine, int* info, void* workspace,
+                        void* stream);
+int vst_cwct_apply_f64(const float* x, float* y, int N, long L, const double* affine, const uint8_t* mask, int label,
+                       void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Measurement hook (bench.py's live roofline figure): bracket every launch of one conv kernel class
  * with HIP events on the launch stream.  One profiling session at a time (begin/end and the launch
@@ -264,6 +300,7 @@ int vst_profile_end(double* total_ms, int* launches);
 /* per-id totals of a VST_KERNEL_ALL (or single-id) session: ids[i], ms[i], launches[i] for i < *n_ids <= cap */
 int vst_profile_end_table(int* ids, double* ms, int* launches, int cap, int* n_ids);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

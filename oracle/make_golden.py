@@ -257,6 +257,39 @@ def main():
     print(f"  batch-coupled jitter: retries for the [2,32,32] content stack = {tj}")
     save("cwct_batch_jitter", c=cj, s=sj, tries=tj, **gj)
 
+    # ------------------------------------------------------------------ use_double=True (cWCT.py:13-16,35-47,66,106,220,238,259)
+    # An ill-conditioned content code (cond(cov) ~ 1e6) so that the fp64 path and the fp32 path differ measurably: the golden is
+    # the reference's fp64 result, which a faithful use_double must hit to ~1e-6 while fp32 arithmetic sits near 1e-3.
+    print("cwct use_double")
+    cwd = ref_cwct.cWCT(use_double=True)
+    N, Hd, Wd = 32, 24, 32
+    gq = torch.Generator().manual_seed(77)
+    q, _ = torch.linalg.qr(torch.randn(N, N, generator=gq, dtype=torch.float64))
+    sv = torch.logspace(0, -3, N, dtype=torch.float64)
+    cd = torch.stack([(q @ (sv[:, None] * torch.randn(N, Hd * Wd, generator=gq, dtype=torch.float64)) + 0.2 * b + 0.1)
+                      for b in range(2)]).float().reshape(2, N, Hd, Wd)
+    sd1 = (rnd((2, N, 16, 24), 960) * torch.linspace(0.3, 1.5, N)[None, :, None, None] + 0.2)
+    sd2 = torch.einsum("ij,bjhw->bihw", torch.eye(N) + 0.2 * rnd((N, N), 961), rnd((2, N, 12, 20), 962)) * 0.6 - 0.1
+    ccen = cd[0].reshape(N, -1).double()
+    ccen = ccen - ccen.mean(-1, keepdim=True)
+    print(f"  cond(cov(content)) = {float(torch.linalg.cond(ccen @ ccen.t() / (Hd * Wd - 1))):.3g}")
+    gd = {"c": cd, "s1": sd1, "s2": sd2}
+    for ac in (0.0, 0.3):
+        o = cwd.interpolation(cd, [sd1, sd2], [0.7, 0.3], ac)
+        assert o.dtype == torch.float32
+        check(f"use_double interpolation alpha_c={ac}", cpu_ref.interpolation(cd, [sd1, sd2], [0.7, 0.3], ac, use_double=True), o, 1e-6)
+        o32 = cw.interpolation(cd, [sd1, sd2], [0.7, 0.3], ac)
+        print(f"  fp32 reference path vs fp64 reference path (alpha_c={ac}): max|d|/max = "
+              f"{float((o32 - o).abs().max() / o.abs().max()):.3e}")
+        gd[f"interp_ac{ac}"] = o
+        gd[f"fp32_path_max_rel_ac{ac}"] = float((o32 - o).abs().max() / o.abs().max())
+    cmd = np.stack([synthetic_mask(Hd, Wd, labels=3, seed=11 + b) for b in range(2)])
+    smd = np.stack([synthetic_mask(16, 24, labels=3, seed=21 + b, speck=False) for b in range(2)])
+    om = cwd.transfer(cd.clone(), sd1.clone(), cmd, smd)
+    check("use_double transfer_seg", cpu_ref.transfer_seg(cd, sd1, cmd, smd, use_double=True), om, 1e-6)
+    gd.update(cmask=cmd, smask=smd, masked=om)
+    save("cwct_double", **gd)
+
     # ------------------------------------------------------------------ mask producers (8(f) rank 3)
     print("segremap")
     spec = importlib.util.spec_from_file_location("reference_segremap", os.path.join(REF, "models", "segmentation", "SegReMapping.py"))

@@ -29,7 +29,8 @@ def L():
     return _lib.lib()
 
 
-def make_net(mode="photo", precision="bf16x3", seed=1234):
+def make_net(mode="photo", precision=None, seed=1234):
+    """precision=None: the PRODUCT default (vstnet_amd._lib.default_precision), i.e. what a user of the drop-in classes runs"""
     from models.RevResNet import RevResNet
     hd, sp = (16, 2) if mode == "photo" else (64, 1)
     net = RevResNet(hidden_dim=hd, sp_steps=sp, precision=precision)
@@ -274,33 +275,40 @@ def test_cwct_mask_errors():
 
 
 # ------------------------------------------------------------------------------------------- whole stylisation
-def test_config1_golden(golden):
+# The BASELINE-config tests run in the product default AND in the fastest opt-in mode, each with its own stated bounds:
+# CFG_MODES = (precision, bound on the codes, bound on the stylised frame, bound on max|inverse(forward(x)) - x|)
+CFG_MODES = [pytest.param("bf16x3", TIGHT, 2e-4, 5e-6, id="bf16x3"), pytest.param("f16x2h", 2.5e-4, 2.5e-4, 1e-4, id="f16x2h")]
+
+
+@pytest.mark.parametrize("precision,tol_z,tol_y,tol_rt", CFG_MODES)
+def test_config1_golden(golden, precision, tol_z, tol_y, tol_rt):
     """BASELINE config 1: photorealistic 256x256, image_transfer.py call sequence."""
     from models.cWCT import cWCT
     g = golden("config1_photo256")
-    net, sd, sp = make_net("photo")
-    cw = cWCT()
+    net, sd, sp = make_net("photo", precision)
+    cw = cWCT(precision=precision)
     xc = synthetic_frames(1, 256, 256, seed=int(g["content_seed"])).cuda()
     xs = synthetic_frames(1, 256, 256, seed=int(g["style_seed"])).cuda()
     zc, zs = net(xc, forward=True), net(xs, forward=True)
     zcs = cw.transfer(zc, zs)
     sty = net(zcs, forward=False)
-    assert_close(zc[:, :, ::8, ::8], T(g["zc_sub"]), TIGHT, "z_c")
-    assert_close(zcs[:, :, ::8, ::8], T(g["zcs_sub"]), 2e-4, "z_cs")
-    l2, mx = assert_close(sty, T(g["stylized"]), 2e-4, "stylized")
+    assert_close(zc[:, :, ::8, ::8], T(g["zc_sub"]), tol_z, "z_c")
+    assert_close(zcs[:, :, ::8, ::8], T(g["zcs_sub"]), max(tol_z, 2e-4), "z_cs")
+    l2, mx = assert_close(sty, T(g["stylized"]), tol_y, "stylized")
     u8 = cpu_ref.to_uint8(sty.cpu())
     d = (u8.int() - T(g["stylized_u8"]).int()).abs()
-    assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 5e-3
+    assert int(d.max()) <= 1 and float((d > 0).float().mean()) < (5e-3 if precision == "bf16x3" else 3e-2)
     stats = lambda t: np.array([float(t.min()), float(t.max()), float(t.double().mean()), float(t.double().std())])
-    assert np.allclose(stats(zc), g["zc_stats"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(stats(zc), g["zc_stats"], rtol=1e-3 if precision != "bf16x3" else 1e-4, atol=1e-4 if precision != "bf16x3" else 1e-5)
     assert np.allclose(stats(zcs), g["zcs_stats"], rtol=1e-3, atol=1e-4)
 
 
-def test_masked_stylisation_vs_oracle():
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2", "f16x2h"])
+def test_masked_stylisation_vs_oracle(precision):
     """config-5 style call (per-region cWCT) at a size the oracle finishes in seconds"""
     from models.cWCT import cWCT
-    net, sd, sp = make_net("photo")
-    cw = cWCT()
+    net, sd, sp = make_net("photo", precision)
+    cw = cWCT(precision=precision)
     H, W = 72, 128
     xc, xs = synthetic_frames(1, H, W, seed=21), synthetic_frames(1, 64, 96, seed=22)
     cm, sm = synthetic_mask(H, W, 5, seed=3)[None], synthetic_mask(64, 96, 5, seed=4, speck=False)[None]
@@ -308,8 +316,9 @@ def test_masked_stylisation_vs_oracle():
         zc, zs, zcs, sty = cpu_ref.stylize(xc, xs, sd, sp, cm, sm)
     g_zc, g_zs = net(xc.cuda()), net(xs.cuda())
     g_zcs = cw.transfer(g_zc, g_zs, cm, sm)
-    assert_close(g_zcs, zcs, 2e-4, "masked z_cs", tol_max=TOL)
-    assert_close(net(g_zcs, forward=False), sty, 2e-4, "masked stylized", tol_max=TOL)
+    tol = 2e-4 if precision == "bf16x3" else 4e-4
+    assert_close(g_zcs, zcs, tol, "masked z_cs", tol_max=TOL)
+    assert_close(net(g_zcs, forward=False), sty, tol, "masked stylized", tol_max=TOL)
 
 
 # ------------------------------------------------------------------------------------------- full size properties
@@ -414,6 +423,75 @@ def test_video_transfer_script_sharded(tmp_path):
         assert np.array_equal(np.asarray(Image.open(os.path.join(outs[0], "00001.png"))), np.asarray(Image.open(single)))
 
 
+@pytest.mark.parametrize("precision", [None, "f16x2h"])
+def test_video_transfer_script_masked(tmp_path, precision):
+    """video_transfer.py with --content_seg / --style_seg (config 5's call) at the product default precision and at f16x2h: the
+    branch the script takes — learnt slot count, per-label maps on the packed rows, applied inside the uint8 decode (under the
+    fp16 modes: half 0 written straight into split planes) — against the oracle, frame by frame; one frame has another size."""
+    from PIL import Image
+    import video_transfer
+    from utils.utils import SEG_COLORS, img_resize, load_segment
+    fd = tmp_path / "clip"
+    fd.mkdir()
+    frames = [_png(fd / f"{i:03d}.png", 64, 96, 20 + i) for i in range(2)] + [_png(fd / "002.png", 48, 80, 29)]
+    style = _png(tmp_path / "s.png", 56, 72, 5)
+    colours = np.array([c for c, _ in SEG_COLORS[:3]], dtype=np.uint8)
+    cseg = colours[synthetic_mask(64, 96, 3, seed=1, speck=False)]
+    sseg = colours[synthetic_mask(56, 72, 3, seed=2, speck=False)]
+    Image.fromarray(cseg).save(tmp_path / "cseg.png")
+    Image.fromarray(sseg).save(tmp_path / "sseg.png")
+    args = ["--video", str(fd), "--style", str(tmp_path / "s.png"), "--out_dir", str(tmp_path / "o"), "--synthetic_weights",
+            "--content_seg", str(tmp_path / "cseg.png"), "--style_seg", str(tmp_path / "sseg.png"), "--frames_only"]
+    out = video_transfer.main(args + (["--precision", precision] if precision else []))
+    names = sorted(os.listdir(out))
+    assert names == ["00000.png", "00001.png", "00002.png"]
+    sd = synthetic_state_dict(1234)
+    tt = lambda a: T(np.ascontiguousarray(a)).permute(2, 0, 1)[None].float().div(255)
+    smask = load_segment(str(tmp_path / "sseg.png"), (72, 56))[None]
+    for i, nme in enumerate(names):
+        got = np.asarray(Image.open(os.path.join(out, nme)))
+        assert got.shape == (64, 96, 3)                                   # the writer size comes from the first frame
+        h, w = frames[i].shape[:2]
+        cmask = load_segment(str(tmp_path / "cseg.png"), (w, h))[None]
+        with torch.no_grad():
+            sty = cpu_ref.stylize(tt(frames[i]), tt(style), sd, 2, cmask, smask)[3]
+        if (h, w) != (64, 96):                                            # resized to the writer size like the script does
+            sty = torch.nn.functional.interpolate(sty, size=(64, 96), mode="bicubic", align_corners=False, antialias=True)
+        ref = cpu_ref.to_uint8(sty)[0].numpy()
+        d = np.abs(got.astype(int) - ref.astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < (1e-2 if precision is None else 5e-2), (i, d.max(), (d > 0).mean())
+
+
+def test_packed_code_inplace_edits_are_not_lost():
+    """a PackedCode 'is a [B,32,H,W] tensor to every caller' — also to one that writes to it.  In-place operations
+    and writes through views land in the materialised tensor; the decode and the cWCT routes must then use those values, not
+    the untouched packed rows."""
+    from models.cWCT import cWCT
+    from vstnet_amd.code import PackedCode
+    net, sd, sp = make_net("photo")
+    dense, _, _ = make_net("photo")
+    dense.packed_code = False
+    cw = cWCT()
+    x, xs = synthetic_frames(1, 32, 48, seed=3).cuda(), synthetic_frames(1, 32, 48, seed=4).cuda()
+    with torch.no_grad():
+        zd, zs = dense(x), dense(xs)
+        z = net(x)
+        assert isinstance(z, PackedCode) and not z.stale
+        z.mul_(1.5)
+        assert z.stale and torch.equal(z.materialize(), zd * 1.5)
+        assert torch.equal(net(z, forward=False), dense(zd * 1.5, forward=False))
+        assert torch.equal(net.inverse_u8(z), dense.inverse_u8(zd * 1.5))
+        z2 = net(x)
+        z2[:, :, 4:9, 7:20] = 0.25                      # a write through a view
+        ed = zd.clone()
+        ed[:, :, 4:9, 7:20] = 0.25
+        assert z2.stale and torch.equal(net(z2, forward=False), dense(ed, forward=False))
+        assert torch.equal(cw.transfer(z2, zs), cw.transfer(ed, zs))      # statistics of the EDITED code
+        z3 = net(x)
+        _ = z3 + 1.0                                    # reading does not invalidate the rows
+        assert not z3.stale and isinstance(cw.transfer(z3, zs), PackedCode)
+
+
 def test_masked_art_mode_with_resized_masks():
     """8(f) rank 3: label maps at image resolution, artistic codes at half resolution -> NEAREST resize (upstream rule)"""
     from models.cWCT import cWCT
@@ -465,12 +543,40 @@ def test_input_forms_and_sample():
     assert not xt.is_contiguous()
     assert torch.equal(net(xt.cuda()), base)
     assert_close(net(x.double().cuda()), base, 1e-7, "fp64 input")
-    with pytest.raises(NotImplementedError):
-        cWCT(use_double=True)                        # no fp64 Cholesky / apply in the HIP path: rejected, not ignored
+    assert cWCT(use_double=True).use_double is True  # implemented: test_cwct_use_double_golden
     out = cWCT().transfer(base.double(), base.double().flip(-1))
     assert out.dtype == torch.float64 and out.shape == base.shape
     xc, xs, xcs, cyc = net.sample(cWCT(), x, synthetic_frames(1, 32, 32, seed=52), "cuda")
     assert xcs.shape == x.shape and cyc.shape == x.shape and torch.isfinite(xcs).all()
+
+
+def test_cwct_use_double_golden(golden):
+    """cWCT(use_double=True) (models/cWCT.py:13-16,35-47,66,106,220,238,259) against goldens minted from the reference with the
+    flag set, on a content code with cond(cov) ~ 1e6: the fp64 path must land on the reference's fp64 result to fp32 output
+    rounding, where fp32 arithmetic (the reference's own fp32 path included: 7e-3 .. 8e-3, recorded in the fixture) cannot."""
+    from models.cWCT import cWCT
+    g = golden("cwct_double")
+    c, s1, s2 = T(g["c"]).cuda(), T(g["s1"]).cuda(), T(g["s2"]).cuda()
+    cwd, cw32 = cWCT(use_double=True), cWCT(precision="fp32")
+    for ac in (0.0, 0.3):
+        ref = T(g[f"interp_ac{ac}"])
+        out = cwd.interpolation(c, [s1, s2], [0.7, 0.3], ac)
+        assert out.dtype == torch.float32 and out.shape == c.shape
+        assert_close(out, ref, 2e-6, f"use_double interpolation alpha_c={ac}")
+        e32 = rel_err(cw32.interpolation(c, [s1, s2], [0.7, 0.3], ac), ref)[1]
+        assert e32 > 1e-4 and float(g[f"fp32_path_max_rel_ac{ac}"]) > 1e-3      # the case separates fp32 from fp64 arithmetic
+    out = cwd.transfer(c.clone(), s1, g["cmask"], g["smask"])
+    assert_close(out, T(g["masked"]), 2e-6, "use_double transfer_seg")
+    assert_close(cwd.transfer(c, s1), cpu_ref.transfer(T(g["c"]), T(g["s1"]), use_double=True), 2e-6, "use_double transfer")
+    # packed codes are materialised, the 2-D helpers run in fp64 too
+    net, sd, sp = make_net("photo")
+    z, zs = net(synthetic_frames(1, 32, 48, seed=1).cuda()), net(synthetic_frames(1, 32, 48, seed=2).cuda())
+    from vstnet_amd.code import PackedCode
+    got = cwd.transfer(z, zs)
+    assert isinstance(z, PackedCode) and not isinstance(got, PackedCode)
+    assert_close(got, cpu_ref.transfer(z.materialize().cpu(), zs.materialize().cpu(), use_double=True), 2e-6, "use_double on a packed code")
+    x2 = T(g["c"])[0].reshape(32, -1)
+    assert_close(cwd.whitening(x2.cuda()), cpu_ref.whitening(x2.double()).float(), 5e-6, "use_double whitening (cond 1e6)")
 
 
 def test_native_runner_matches_python_path(tmp_path):
@@ -489,7 +595,7 @@ def test_native_runner_matches_python_path(tmp_path):
         s = torch.randint(0, 256, (1, 32, 48, 3), dtype=torch.uint8, generator=g)
         c.numpy().tofile(tmp_path / "c.rgb"); s.numpy().tofile(tmp_path / "s.rgb")
         r = subprocess.run([_lib.RUNNER_BIN, str(tmp_path / "w.bin"), str(tmp_path / "c.rgb"), "40", "64",
-                            str(tmp_path / "s.rgb"), "32", "48", str(tmp_path / "o.rgb")] + ([] if precision == "f16x2h" else [precision]),
+                            str(tmp_path / "s.rgb"), "32", "48", str(tmp_path / "o.rgb"), precision],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr + r.stdout
         got = np.fromfile(tmp_path / "o.rgb", dtype=np.uint8).reshape(40, 64, 3)
@@ -589,12 +695,13 @@ def _cov(m):
     return d @ d.t() / (m.shape[1] - 1)
 
 
-def test_full_size_config3_art_batch4():
+@pytest.mark.parametrize("precision,tol_z,tol_y,tol_rt", CFG_MODES)
+def test_full_size_config3_art_batch4(precision, tol_z, tol_y, tol_rt):
     """config 3's per-GPU share: artistic mode, 4 frames of 1024x1024 in one batch.  Properties: every frame of the
     batch equals the same frame run alone (bit for bit), the pass inverts, the code takes the style's moments."""
     from models.cWCT import cWCT
-    net, sd, sp = make_net("art")
-    cw = cWCT()
+    net, sd, sp = make_net("art", precision)
+    cw = cWCT(precision=precision)
     x = synthetic_frames(4, 1024, 1024, seed=3).cuda()
     xs = synthetic_frames(1, 1024, 1024, seed=1).cuda()
     with torch.no_grad():
@@ -602,7 +709,7 @@ def test_full_size_config3_art_batch4():
         assert z.shape == (4, 128, 512, 512)
         z1 = net(x[2:3])
         assert torch.equal(z[2:3], z1)
-        assert float((net(z, forward=False) - x).abs().max()) < 5e-6
+        assert float((net(z, forward=False) - x).abs().max()) < tol_rt
         stats = cw.style_stats(net(xs))
         zcs = cw.transfer_with_stats(z, stats)
         zs = net(xs)[0].reshape(128, -1).double()
@@ -614,18 +721,25 @@ def test_full_size_config3_art_batch4():
         assert torch.isfinite(sty).all() and sty.shape == x.shape
 
 
-def test_full_size_config4_4096():
+@pytest.mark.parametrize("precision,tol_z,tol_y,tol_rt", CFG_MODES)
+def test_full_size_config4_4096(precision, tol_z, tol_y, tol_rt):
     """config 4: one 4096x4096 photorealistic image on one GPU (2 GiB of state per half; the pass runs in sub-batches
-    sized for the Infinity Cache).  Properties: invertibility, style moments, and the top-left 512x512 of the code
-    equals the code of the top-left 640x640 crop there (receptive field 30 blocks x 3 convs = 90 px < 128)."""
+    sized for the Infinity Cache).  The code's top-left 512x512 against the ORACLE run on the top-left 640x640 crop (the
+    receptive field of 30 blocks x 3 convs is 90 px < 128: that corner of the code does not see beyond the crop), then
+    properties: invertibility, crop consistency on the GPU, style moments."""
     from models.cWCT import cWCT
-    net, sd, sp = make_net("photo")
-    cw = cWCT()
-    x = synthetic_frames(1, 4096, 4096, seed=11).cuda()
+    net, sd, sp = make_net("photo", precision)
+    cw = cWCT(precision=precision)
+    x_cpu = synthetic_frames(1, 4096, 4096, seed=11)
+    with torch.no_grad():
+        torch.set_num_threads(16)
+        z_or = cpu_ref.revnet_forward(x_cpu[:, :, :640, :640].contiguous(), sd, sp)[:, :, :512, :512]
+    x = x_cpu.cuda()
     xs = synthetic_frames(1, 1024, 1024, seed=1).cuda()
     with torch.no_grad():
         z = net(x)
-        assert float((net(z, forward=False) - x).abs().max()) < 5e-6
+        assert_close(z[:, :, :512, :512], z_or, tol_z, f"4096x4096 code, 512x512 corner vs oracle ({precision})")
+        assert float((net(z, forward=False) - x).abs().max()) < tol_rt
         zc = net(x[:, :, :1024, :1024].contiguous())
         d = (z[:, :, :512, :512] - zc[:, :, :512, :512]).abs().max()
         assert float(d) < 1e-4 * float(zc.abs().max())           # same arithmetic, different tile grid -> fp32 noise only
@@ -639,14 +753,15 @@ def test_full_size_config4_4096():
         assert out.shape == (1, 4096, 4096, 3) and out.dtype == torch.uint8
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2h"])
 @pytest.mark.parametrize("kind", ["bands", "noise"])
-def test_full_size_config5_1080p_masked(kind):
+def test_full_size_config5_1080p_masked(kind, precision):
     """config 5's frame: 1920x1080, 5-label masks (+ a 6-pixel speck that must stay untouched) — vertical bands, and the
     worst case for anything per-label: an independent random label per pixel.  Property: inside every valid label the
     transferred code has the moments of the style code inside the same label; the speck keeps the content code."""
     from models.cWCT import cWCT
-    net, sd, sp = make_net("photo")
-    cw = cWCT()
+    net, sd, sp = make_net("photo", precision)
+    cw = cWCT(precision=precision)
     H, W = 1080, 1920
     x = synthetic_frames(1, H, W, seed=21).cuda()
     xs = synthetic_frames(1, H, W, seed=22).cuda()
@@ -664,6 +779,24 @@ def test_full_size_config5_1080p_masked(kind):
         assert float((_cov(a) - _cov(b)).abs().max() / _cov(b).abs().max()) < 2e-4, label
     speck = cmt == 5
     assert int(speck.sum()) == 6 and torch.equal(a_all[:, speck], c_all[:, speck])
+    # the encode against the ORACLE on the top-left 640x640 crop (512x512 corner of the code: receptive field 90 px < 128),
+    # the masked cWCT against the oracle's transfer_seg fed with the same codes, and the route video_transfer.py takes
+    # (learnt slot count -> per-label maps on the packed rows, applied inside the uint8 decode) against the dense route
+    tol_z = TIGHT if precision == "bf16x3" else 2.5e-4
+    with torch.no_grad():
+        torch.set_num_threads(16)
+        x_cpu = x.cpu()
+        z_or = cpu_ref.revnet_forward(x_cpu[:, :, :640, :640].contiguous(), sd, sp)[:, :, :512, :512]
+        assert_close(zc0[:, :, :512, :512], z_or, tol_z, f"1080p code corner vs oracle ({precision})")
+        ref = cpu_ref.transfer_seg(zc0.cpu(), zs.cpu(), cm, sm)
+        assert_close(zcs, ref, 2e-4, f"1080p masked cWCT vs oracle ({kind})", tol_max=TOL)
+        plan = cw.bind_style(cw.learn_slots(cw.plan_masks(cm, sm, zc.shape, zs.shape, zc.device)), zs)
+        t = cw.transfer_with_plan(net(x), None, plan)
+        from vstnet_amd.code import PackedCode
+        assert isinstance(t, PackedCode) and t.pending_labels is not None
+        u8_packed, u8_dense = net.inverse_u8(t), net.inverse_u8(zcs)
+        dd = (u8_packed.int() - u8_dense.int()).abs()
+        assert int(dd.max()) <= 1 and float((dd > 0).float().mean()) < (1e-3 if precision == "bf16x3" else 2e-2)
 
 
 # ------------------------------------------------------------------------------------------- full size vs the oracle itself
@@ -929,17 +1062,21 @@ def test_packed_code_equals_dense_path(precision):
     assert_close(got, ref, NET_TOL[precision], "stylised frame through the packed code vs oracle")
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2", "f16x2h"])
 @pytest.mark.parametrize("kind", ["bands", "noise"])
-def test_packed_code_masked_transfer(kind):
+def test_packed_code_masked_transfer(kind, precision):
     """transfer_with_plan on a PackedCode: per-label statistics and per-row affine maps on the packed rows (label map
     permuted once per plan into the rows' order), applied by the inverse pass.  Against the dense masked route, and against
     the oracle; 3..8 labels incl. a speck (invalid label: its rows keep their values), a batch, region and per-pixel masks."""
     from models.cWCT import cWCT
     from vstnet_amd.code import PackedCode
-    net, sd, sp = make_net("photo", "bf16x3")
+    # (under the fp16 modes the decode takes its own branch: the per-row maps write half 0 straight into split fp16 planes,
+    # cwct_apply_labels_pm_kernel with planes0, and the inverse pass reads that half only through them)
+    net, sd, sp = make_net("photo", precision)
     net.packed_code = "always"
-    dense, _, _ = make_net("photo", "bf16x3")
+    dense, _, _ = make_net("photo", precision)
     dense.packed_code = False
+    tol_out = 1e-4 if precision == "bf16x3" else 3e-4      # fp16 intermediates turn 1e-6 differences of z_cs into fp16 steps
     cw = cWCT(precision="fp32")                  # dense masked apply in exact fp32 too: the two routes then differ by rounding only
     for B, H, W, K in ((1, 64, 96, 3), (2, 40, 24, 4), (1, 128, 192, 5), (1, 96, 96, 8)):
         x, xs = synthetic_frames(B, H, W, seed=2).cuda(), synthetic_frames(B, H, W, seed=3).cuda()
@@ -952,12 +1089,16 @@ def test_packed_code_masked_transfer(kind):
             assert isinstance(t, PackedCode) and t.pending_labels is not None and not isinstance(td, PackedCode)
             # (two summation orders of the per-label statistics; small regions have ill-conditioned covariances that amplify it)
             assert_close(t.materialize(), td, 1e-5, f"masked transfer on packed rows {kind} {B}x{H}x{W} K={K}", tol_max=1e-4)
-            assert float((net(t, forward=False) - dense(td, forward=False)).abs().max()) <= 1e-4
+            out_packed = net(t, forward=False)
+            assert float((out_packed - dense(td, forward=False)).abs().max()) <= tol_out
             assert int((net.inverse_u8(t).int() - dense.inverse_u8(td).int()).abs().max()) <= 1
             bound = cw.bind_style(cw.learn_slots(cw.plan_masks(cm, sm, z.shape, zs.shape, z.device)), zs)
             assert_close(cw.transfer_with_plan(z, None, bound).materialize(), td, 1e-5, "bound style", tol_max=1e-4)
             ref = cpu_ref.transfer_seg(zd.cpu(), zs.cpu(), cm, sm)
+            ref_out = cpu_ref.revnet_inverse(ref, sd, sp)
         assert_close(t.materialize(), ref, 2e-4, f"masked packed transfer vs oracle {kind} K={K}", tol_max=TOL)
+        # and the decode of the pending-labels code against the ORACLE's inverse of the oracle's masked transfer
+        assert_close(out_packed, ref_out, 3e-4, f"decode of the masked packed code vs oracle {kind} K={K} ({precision})", tol_max=TOL)
     # more than 8 slots, or a plan whose slot count was never read back: the dense route takes over
     H, W, K = 96, 128, 11
     x, xs = synthetic_frames(1, H, W, seed=2).cuda(), synthetic_frames(1, H, W, seed=3).cuda()

@@ -32,8 +32,23 @@ def test_header_symbols_exported(lib):
         assert hasattr(lib, name), name
 
 
+def test_library_exports_only_the_header(lib):
+    """ABI hygiene: the shared library's exported FUNCTIONS are exactly the header's declarations — no
+    internal helper (vst3_*, vst_pack_input_k, ...) and none of the diagnostic scaffolding (vst_trace_dump of -DVST_TRACE
+    builds) — and build() passes no -DVST_* flag, so the ablation / trace branches are compiled out of what ships."""
+    import inspect
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    funcs = {ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "TtWw"}
+    funcs = {f for f in funcs if not f.startswith("_")}                   # (_init / _fini)
+    assert funcs == set(_lib.EXPORTS), funcs ^ set(_lib.EXPORTS)
+    assert "vst_trace_dump" not in out and "vst3_" not in " ".join(funcs)
+    src = inspect.getsource(_lib.build)
+    assert "-DVST" not in src and "-D" not in src.replace("-DVST", "")
+
+
 def test_sizes_and_errors_without_gpu(lib):
-    assert lib.vst_version() >= 100
+    assert lib.vst_version() >= 101
     # two state halves (64 B/px each) + h1/h2 (32 B/px) + the split planes of both halves for the F16X2 kernels (2 x 64 B/px)
     assert lib.vst_pass_workspace_bytes(1, 1024, 1024) == 1024 * 1024 * 288
     assert lib.vst_block_tmp_bytes(2, 64, 32) == 2 * 64 * 32 * 160
@@ -53,6 +68,12 @@ def test_sizes_and_errors_without_gpu(lib):
     assert lib.vst_spread(one, one, one, 1, 16, 16, 3, null) == -3
     assert lib.vst_cwct_apply(one, one, 48, 100, one, null, 0, null) == -2
     assert lib.vst_cwct_stats(one, 32, 100, null, 0, one, null, null) == -4
+    assert lib.vst_cwct_stats_f64(one, 32, 100, null, 0, one, null, null) == -4
+    assert lib.vst_cwct_stats_f64_workspace_bytes(32, 4096) == 2 * (33 + 1024) * 8
+    assert lib.vst_cwct_factor_f64_workspace_bytes(128) == 4 * 128 * 128 * 8
+    assert lib.vst_cwct_apply_f64(one, one, 48, 100, one, null, 0, null) == -2
+    assert lib.vst_normalize_block(one, one, one, one, one, 16, 65, 16, null, null) == -2
+    assert lib.vst_range_flags(None, 0) == -1
     net = _lib.NetWeights()
     assert lib.vst_revnet_forward(C.byref(net), one, one, null, 1, 3, 16, 16, 2, 0, null) == -4
     assert lib.vst_revnet_forward(C.byref(net), one, one, one, 1, 3, 16, 16, 5, 0, null) == -3

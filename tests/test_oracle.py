@@ -166,3 +166,18 @@ def test_lab_luminance(golden):
     gray = c.mean(1, keepdim=True).expand(-1, 3, -1, -1)
     lab = cpu_ref._rgb2lab(gray)
     assert float(lab[:, 1:].abs().max()) < 2e-3                       # greys have no chroma
+
+
+def test_cwct_use_double(golden):
+    """oracle with use_double=True against the goldens minted from the reference's cWCT(use_double=True)
+    (models/cWCT.py:13-16,35-47,66,106,220,238,259) on an ill-conditioned content code (cond(cov) ~ 1e6)"""
+    g = golden("cwct_double")
+    c, s1, s2 = T(g["c"]), T(g["s1"]), T(g["s2"])
+    for ac in (0.0, 0.3):
+        out = cpu_ref.interpolation(c, [s1, s2], [0.7, 0.3], ac, use_double=True)
+        assert out.dtype == torch.float32
+        close(out, T(g[f"interp_ac{ac}"]), 1e-6)
+        # the case separates the arithmetics: the oracle's fp32 path is ~1e-2 away from the fp64 golden
+        d32 = (cpu_ref.interpolation(c, [s1, s2], [0.7, 0.3], ac) - T(g[f"interp_ac{ac}"])).abs().max()
+        assert float(d32) > 1e-3
+    close(cpu_ref.transfer_seg(c, s1, g["cmask"], g["smask"], use_double=True), T(g["masked"]), 1e-6)

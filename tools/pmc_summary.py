@@ -2,7 +2,8 @@
 the per-kernel HBM-traffic summary kept under profiles/ (MI355X_MICROARCH.md, HBM section: FETCH_SIZE is in KB and
 counts 64 B per 128-B request on gfx950 wide coalesced reads -> doubled; WRITE_SIZE in KB, exact).
 
-  python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_hbm_traffic.json "<command>" "<workload>"
+  python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r03_pmc_hbm_traffic.json "<command>" "<workload>" \
+      [precision] [git commit]      (the last two are what bench.py's roofline.traffic_source reports)
 """
 import collections
 import csv
@@ -22,7 +23,7 @@ def per_kernel(prof_dir, counter):
     return {k: (tot[k], len(disp[k])) for k in tot}
 
 
-def main(fetch_dir, write_dir, dest, command, workload):
+def main(fetch_dir, write_dir, dest, command, workload, precision=None, git_commit=None):
     fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
     kernels = {}
     for k, (fkb, n) in fetch.items():
@@ -34,10 +35,11 @@ def main(fetch_dir, write_dir, dest, command, workload):
                "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads -> doubled "
                              "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact. Both are L2 memory-side request "
                              "counters: Infinity-Cache hits are included.",
-               "workload": workload, "kernels": kernels}, open(dest, "w"), indent=1)
+               "workload": workload, "precision": precision, "git_commit": git_commit, "kernels": kernels},
+              open(dest, "w"), indent=1)
     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:14]:
         print(f"{k[:70]:70s} n={v['launches']:4d} {v['hbm_bytes_per_launch'] / 2 ** 20:8.1f} MiB/launch")
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:6])
+    main(*sys.argv[1:8])

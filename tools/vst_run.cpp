@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
         fprintf(stderr, "usage: %s weights.bin content.rgb H W style.rgb Hs Ws out.rgb [f16x2h|f16x2|bf16x3|fp32]\n", argv[0]);
         return 1;
     }
-    int prec = VST_PREC_F16X2H;                   // the drop-in classes' default
+    int prec = VST_PREC_BF16X3;                   // the drop-in classes' default (fp32-class; the fp16 modes are opt-in)
     if (argc == 10) {
         if (!strcmp(argv[9], "bf16x3")) prec = VST_PREC_BF16X3;
         else if (!strcmp(argv[9], "fp32")) prec = VST_PREC_FP32;
@@ -63,19 +63,24 @@ int main(int argc, char** argv) {
     for (int k = 0; k < VST_NUM_BLOCKS; ++k) {
         const int ch = k < 10 ? 16 : (k < 20 ? 64 : 256), stride = (k == 10 || k == 20) ? 2 : 1;
         const int cin[3] = {stride == 1 ? ch : ch / 4, ch / 4, ch / 4}, cout[3] = {ch / 4, ch / 4, ch};
+        float* dw[3];
+        float* db[3];
         for (int c = 0; c < 3; ++c) {
             const size_t nw = (size_t)cout[c] * cin[c] * 9;
-            float *dw, *db;
+            HIP_OK(hipMalloc(&dw[c], nw * 4));
+            HIP_OK(hipMalloc(&db[c], cout[c] * 4));
+            HIP_OK(hipMemcpyAsync(dw[c], wp, nw * 4, hipMemcpyHostToDevice, st)); wp += nw;
+            HIP_OK(hipMemcpyAsync(db[c], wp, cout[c] * 4, hipMemcpyHostToDevice, st)); wp += cout[c];
+            keep.push_back(dw[c]);
+        }
+        // the same exponent normalisation of h1 / h2 the Python classes apply at pack time (exact, function-preserving)
+        VST_CALL(vst_normalize_block(dw[0], db[0], dw[1], db[1], dw[2], cin[0], cout[0], cout[2], nullptr, st));
+        for (int c = 0; c < 3; ++c) {
             void* packed;
-            HIP_OK(hipMalloc(&dw, nw * 4));
-            HIP_OK(hipMalloc(&db, cout[c] * 4));
             HIP_OK(hipMalloc(&packed, vst_conv_packed_bytes(cout[c], cin[c])));
-            HIP_OK(hipMemcpyAsync(dw, wp, nw * 4, hipMemcpyHostToDevice, st)); wp += nw;
-            HIP_OK(hipMemcpyAsync(db, wp, cout[c] * 4, hipMemcpyHostToDevice, st)); wp += cout[c];
-            VST_CALL(vst_pack_conv(dw, cout[c], cin[c], packed, st));
+            VST_CALL(vst_pack_conv(dw[c], cout[c], cin[c], packed, st));
             net.blocks[k].conv[c].packed = packed;
-            net.blocks[k].conv[c].bias = db;
-            keep.push_back(dw);
+            net.blocks[k].conv[c].bias = db[c];
         }
     }
     if ((const uint8_t*)wp != wfile.data() + wfile.size()) { fprintf(stderr, "weights file has the wrong length\n"); return 1; }
@@ -116,6 +121,10 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> out(content.size());
     HIP_OK(hipMemcpyAsync(out.data(), d_out, out.size(), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
+    unsigned range = 0;
+    VST_CALL(vst_range_flags(&range, 0));
+    if (range) fprintf(stderr, "vst_run: WARNING fp16 range flags 0x%x (1 = an activation saturated at +-65504, 2 = a weight beyond fp16): "
+                               "rerun with bf16x3\n", range);
     FILE* f = fopen(argv[8], "wb");
     if (!f || fwrite(out.data(), 1, out.size(), f) != out.size()) { fprintf(stderr, "cannot write %s\n", argv[8]); return 1; }
     fclose(f);

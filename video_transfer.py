@@ -8,9 +8,18 @@ H2D, compute, D2H and encode overlap (vstnet_amd/pipeline.py) instead of running
 reference is kept (:83-86: video_width is overwritten before it scales video_height, so a 1920x1080 clip at
 --max_size 1280 is written at 1280x1080 while frames are stylised at 1280x720).
 --video may be a directory of frames (always works) or a video file (needs cv2, optional).  Output: an .mp4 if
-cv2 is importable, else numbered PNGs.  --shard i/n processes the i-th contiguous shard of the frames (one
-process per GPU; frames are independent).
+cv2 is importable, else numbered PNGs.
+
+Multi-GPU (BASELINE config 5; SURVEY 8(e): frames are independent, the host gathers the outputs):
+  --gpus N     this process starts N children BEFORE it touches a GPU — child r gets HIP_VISIBLE_DEVICES=r, a CPU thread cap
+               of cores // N and `--shard r/N` —, waits for all of them (a failing child fails the run: non-zero exit, the
+               others are terminated, nothing is re-executed) and then merges their outputs into the ONE ordered clip / frame
+               directory the reference writes (video_transfer.py:92-96,160-214): every frame index present exactly once.
+  --shard i/n  process the i-th contiguous shard of the frames (what the children run; also usable by hand).
+Every frame is resized on its own like the reference's loop (:161): a frame whose size differs from its predecessor's gets its
+own ring buffers and mask plan instead of an error; the writer size comes from the clip's first frame (:82-86).
 """
+import sys
 import argparse
 import os
 
@@ -42,6 +51,11 @@ def build_parser():
     p.add_argument('--auto_seg', action='store_true', default=False)
     p.add_argument('--synthetic_weights', action='store_true', default=False)
     p.add_argument('--shard', type=str, default="0/1")
+    p.add_argument('--gpus', type=int, default=1, help="start this many child processes, one GPU each, and merge their outputs")
+    p.add_argument('--precision', type=str, default=None, help="conv arithmetic (default: the library's, bf16x3)")
+    p.add_argument('--frames_only', action='store_true', default=False, help="write numbered PNGs even if cv2 is there "
+                   "(what the children of --gpus N do: the parent encodes the one clip)")
+    p.add_argument('--stub_stylise', action='store_true', default=False, help=argparse.SUPPRESS)   # host-logic tests: no GPU
     p.add_argument('--depth', type=int, default=4, help="pinned ring slots (frames queued ahead of the one being written)")
     p.add_argument('--streams', type=int, default=2, help="frames in flight on the card")
     return p
@@ -73,53 +87,66 @@ def writer_size(first_frame, max_size):
     return video_width, video_height
 
 
-def main(argv=None):
-    args = build_parser().parse_args(argv)
-    if args.auto_seg:
-        raise NotImplementedError("--auto_seg needs mmseg/SegFormer (not part of this repository)")
-    device = torch.device("cuda")
-    os.makedirs(args.out_dir, exist_ok=True)
-    net = build_network(args.mode, args.ckpoint, args.synthetic_weights, device)
-    from models.cWCT import cWCT
-    cwct = cWCT()
+def clip_name(args):
+    return "%s_%s" % (os.path.basename(args.video.rstrip("/")).split(".")[0], os.path.basename(args.style).split(".")[0])
 
-    frames = read_frames(args.video)
-    rank, world = (int(v) for v in args.shard.split("/"))
-    lo, hi = shard_range(len(frames), rank, world)
-    video_width, video_height = writer_size(frames[0], args.max_size)
 
-    style = img_resize(Image.open(args.style).convert('RGB'), args.max_size, down_scale=net.down_scale)
-    masked = args.content_seg is not None and args.style_seg is not None
-    with torch.no_grad():
-        z_s = net.forward_u8(to_tensor_u8(style).to(device))
-        s_stats = cwct.style_stats(z_s) if not masked and args.alpha_c is None else None
-    style_seg = load_segment(args.style_seg, style.size)[None, ...] if masked else None
+def launch_shards(args, argv):
+    """--gpus N: N children, one per GPU, each on its contiguous shard; decided before this process touches a GPU."""
+    from vstnet_amd.sharding import launch_children, rank_environment
+    n = args.gpus
+    base = [a for a in argv]
+    for flag in ("--gpus", "--shard"):                  # children get their own --shard and no --gpus
+        while flag in base:
+            i = base.index(flag)
+            del base[i:i + 2]
+    base = [a for a in base if not a.startswith("--gpus=") and not a.startswith("--shard=")]
+    cmds = [[sys.executable, os.path.abspath(__file__)] + base + ["--shard", "%d/%d" % (r, n), "--frames_only"] for r in range(n)]
+    return launch_children(cmds, [rank_environment(r, n, visible_device=True) for r in range(n)])
 
-    name = "%s_%s" % (os.path.basename(args.video.rstrip("/")).split(".")[0], os.path.basename(args.style).split(".")[0])
-    writer, frame_dir = None, None
+
+def merge_outputs(frame_dir, n_frames, out_dir, name, fps, size):
+    """The host side of SURVEY 8(e): the shards wrote frame i as <frame_dir>/%05d.png; check that every index 0..n-1 is there
+    exactly once, then — with cv2 — encode the ONE clip <out_dir>/<name>.mp4 in frame order (one lossy encode, like the
+    reference's single writer) and drop the PNGs; without cv2 the ordered frame directory is the output."""
+    have = sorted(f for f in os.listdir(frame_dir) if f.endswith(".png"))
+    want = ["%05d.png" % i for i in range(n_frames)]
+    if have != want:
+        missing = sorted(set(want) - set(have))
+        extra = sorted(set(have) - set(want))
+        raise RuntimeError(f"merge: {len(missing)} frames missing (first {missing[:3]}), {len(extra)} unexpected (first {extra[:3]})")
     try:
         import cv2
-        writer = cv2.VideoWriter(os.path.join(args.out_dir, name + (".mp4" if world == 1 else "_%d.mp4" % rank)),
-                                 cv2.VideoWriter_fourcc('m', 'p', '4', 'v'), args.fps, (video_width, video_height))
     except ImportError:
-        frame_dir = os.path.join(args.out_dir, name)
-        os.makedirs(frame_dir, exist_ok=True)
+        return frame_dir
+    path = os.path.join(out_dir, name + ".mp4")
+    writer = cv2.VideoWriter(path, cv2.VideoWriter_fourcc('m', 'p', '4', 'v'), fps, size)
+    try:
+        for f in want:
+            writer.write(np.asarray(Image.open(os.path.join(frame_dir, f)).convert('RGB'))[..., ::-1])
+    finally:
+        writer.release()
+    for f in want:
+        os.remove(os.path.join(frame_dir, f))
+    os.rmdir(frame_dir)
+    return path
 
-    def write(i, out):
-        if writer is not None:
-            writer.write(out[..., ::-1])
-        else:
-            Image.fromarray(out).save(os.path.join(frame_dir, "%05d.png" % i))
 
-    if hi > lo:
-        first = img_resize(frames[lo], args.max_size, down_scale=net.down_scale)
-        content_seg = load_segment(args.content_seg, first.size)[None, ...] if masked else None
-        cw_, ch_ = first.size
+class _SizeContext:
+    """Everything that depends on the stylised frame size: ring buffers / streams (FramePipeline), the mask plan, the decode
+    hook that resizes to the writer size.  One per distinct size met in the clip (normally exactly one)."""
+
+    def __init__(self, args, net, cwct, z_s, s_stats, style_seg, size_wh, writer_wh, device):
+        cw_, ch_ = size_wh
+        video_width, video_height = writer_wh
+        masked = style_seg is not None
+        self.size = size_wh
         plan = None
         if masked:      # one label map for every frame and one style: histograms, uploads and the style side happen once
+            content_seg = load_segment(args.content_seg, size_wh)[None, ...]
             with torch.no_grad():
                 zc_shape = (1, 32, ch_, cw_) if net.sp_steps == 2 else (1, 128, ch_ // 2, cw_ // 2)
-                # (learn_slots: one read-back per clip; with at most 8 labels the masked transfer then stays on the packed code)
+                # (learn_slots: one read-back per size; with at most 8 labels the masked transfer then stays on the packed code)
                 plan = cwct.bind_style(cwct.learn_slots(cwct.plan_masks(content_seg, style_seg, zc_shape, z_s.shape, device)), z_s)
 
         def transform(z_c, i):
@@ -136,29 +163,101 @@ def main(argv=None):
                 sty = net(z_cs, forward=False)
                 sty = F.interpolate(sty, size=(video_height, video_width), mode="bicubic", align_corners=False, antialias=True)
                 return sty.mul(255).clamp(0, 255).byte().permute(0, 2, 3, 1).contiguous()
+        self.pipe = FramePipeline(net, transform, ch_, cw_, device=device, depth=args.depth, compute_streams=args.streams,
+                                  decode=decode, out_height=video_height, out_width=video_width)
 
-        def source():        # decode + resize in a background thread (img_resize: utils/utils.py:90-101)
-            for i in range(lo, hi):
-                arr = np.asarray(img_resize(frames[i], args.max_size, down_scale=net.down_scale), dtype=np.uint8)
-                if arr.shape[:2] != (ch_, cw_):     # the pinned ring, the mask plan and the writer are sized once per clip
-                    raise ValueError(f"frame {i} resizes to {arr.shape[1]}x{arr.shape[0]}, the clip's first frame to "
-                                     f"{cw_}x{ch_}: frames of one clip must share a size")
-                yield arr
 
-        pipe = FramePipeline(net, transform, ch_, cw_, device=device, depth=args.depth, compute_streams=args.streams,
-                             decode=decode, out_height=video_height, out_width=video_width)
-        sink = AsyncSink(write)
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = build_parser().parse_args(argv)
+    if args.auto_seg:
+        raise NotImplementedError("--auto_seg needs mmseg/SegFormer (not part of this repository)")
+    os.makedirs(args.out_dir, exist_ok=True)
+    name = clip_name(args)
+    frames = read_frames(args.video)
+    video_width, video_height = writer_size(frames[0], args.max_size)
+
+    if args.gpus > 1:                                   # parent of a multi-GPU run: never initialises a GPU itself
+        rc = launch_shards(args, argv)
+        if rc != 0:
+            raise SystemExit(rc)
+        out = merge_outputs(os.path.join(args.out_dir, name), len(frames), args.out_dir, name, args.fps, (video_width, video_height))
+        print("Save stylized video at %s" % out)
+        return out
+
+    rank, world = (int(v) for v in args.shard.split("/"))
+    lo, hi = shard_range(len(frames), rank, world)
+    down_scale = 4
+    net = cwct = z_s = s_stats = style_seg = device = None
+    masked = args.content_seg is not None and args.style_seg is not None
+    if not args.stub_stylise:
+        device = torch.device("cuda")
+        net = build_network(args.mode, args.ckpoint, args.synthetic_weights, device, args.precision)
+        down_scale = net.down_scale
+        from models.cWCT import cWCT
+        cwct = cWCT(precision=args.precision)
+        style = img_resize(Image.open(args.style).convert('RGB'), args.max_size, down_scale=down_scale)
+        with torch.no_grad():
+            z_s = net.forward_u8(to_tensor_u8(style).to(device))
+            s_stats = cwct.style_stats(z_s) if not masked and args.alpha_c is None else None
+        style_seg = load_segment(args.style_seg, style.size)[None, ...] if masked else None
+
+    writer, frame_dir = None, None
+    cv2 = None
+    if not args.frames_only:
         try:
-            pipe.run(prefetch(source(), ahead=args.depth), sink, start_index=lo)
+            import cv2
+        except ImportError:
+            cv2 = None
+    if cv2 is not None:
+        writer = cv2.VideoWriter(os.path.join(args.out_dir, name + (".mp4" if world == 1 else "_%d.mp4" % rank)),
+                                 cv2.VideoWriter_fourcc('m', 'p', '4', 'v'), args.fps, (video_width, video_height))
+    else:
+        frame_dir = os.path.join(args.out_dir, name)
+        os.makedirs(frame_dir, exist_ok=True)
+
+    def write(i, out):
+        if writer is not None:
+            writer.write(out[..., ::-1])
+        else:
+            Image.fromarray(out).save(os.path.join(frame_dir, "%05d.png" % i))
+
+    def source():        # decode + resize in a background thread; EVERY frame is resized on its own (video_transfer.py:161)
+        for i in range(lo, hi):
+            yield i, np.asarray(img_resize(frames[i], args.max_size, down_scale=down_scale), dtype=np.uint8)
+
+    sink = AsyncSink(write)
+    try:
+        if args.stub_stylise:       # host-logic rehearsal: the "stylised" frame is the resized frame at the writer size
+            for i, arr in source():
+                sink(i, np.asarray(Image.fromarray(arr).resize((video_width, video_height), Image.BICUBIC)))
+        else:
+            # consecutive frames of one size stream through that size's pipeline; a size change (rare: the reference resizes
+            # every frame on its own, :161) drains it and switches to the other size's context
+            contexts = {}
+            it = iter(prefetch(source(), ahead=args.depth))
+            pending = next(it, None)
+            while pending is not None:
+                size_wh, start = (pending[1].shape[1], pending[1].shape[0]), pending[0]
+
+                def same_size_run():
+                    nonlocal pending
+                    while pending is not None and (pending[1].shape[1], pending[1].shape[0]) == size_wh:
+                        arr = pending[1]
+                        pending = next(it, None)
+                        yield arr
+                ctx = contexts.get(size_wh)
+                if ctx is None:
+                    ctx = contexts[size_wh] = _SizeContext(args, net, cwct, z_s, s_stats, style_seg, size_wh,
+                                                           (video_width, video_height), device)
+                ctx.pipe.run(same_size_run(), sink, start_index=start)
+    finally:
+        try:
+            sink.close()
         finally:
-            try:
-                sink.close()
-            finally:
-                if writer is not None:
-                    writer.release()
-                    writer = None
-    if writer is not None:
-        writer.release()
+            if writer is not None:
+                writer.release()
+                writer = None
     print("Save stylized video at %s" % (frame_dir or args.out_dir))
     return frame_dir or args.out_dir
 

@@ -35,7 +35,25 @@ EXPORTS = [
     "vst_cwct_stats_code_workspace_bytes", "vst_cwct_stats_code", "vst_cwct_apply_code",
     "vst_mask_to_code", "vst_cwct_stats_labels_code_workspace_bytes", "vst_cwct_stats_labels_code", "vst_cwct_apply_labels_code",
     "vst_revnet_decode_labels", "vst_revnet_decode_labels_u8", "vst_pass_sub_batch",
+    "vst_normalize_block", "vst_range_flags",
+    "vst_cwct_stats_f64_workspace_bytes", "vst_cwct_stats_f64", "vst_cwct_factor_f64_workspace_bytes", "vst_cwct_factor_f64",
+    "vst_cwct_apply_f64",
 ]
+RANGE_SATURATED = 1
+RANGE_WEIGHT = 2
+
+
+PRECISIONS = {"bf16x3": PREC_BF16X3, "fp32": PREC_FP32, "f16x2": PREC_F16X2, "f16x2h": PREC_F16X2H}
+
+
+def default_precision() -> str:
+    """bf16x3: the fp32-class arithmetic (3e-6 of the reference).  The fp16 modes are opt-in (per module, or VST_PRECISION):
+    they round the weights to 11 bits, which DESIGN.md section 3 prices at 1.5e-4 on well-conditioned codes and at more than
+    the 1e-3 budget on ill-conditioned ones (tests/test_gpu_robust.py)."""
+    p = os.environ.get("VST_PRECISION", "bf16x3")
+    if p not in PRECISIONS:
+        raise ValueError(f"VST_PRECISION must be one of {sorted(PRECISIONS)}")
+    return p
 
 
 class VstError(RuntimeError):
@@ -60,7 +78,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest_src:
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
+    # host code with hidden default visibility: the shared library exports exactly what include/vstnet.h declares
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-Xarch_host", "-fvisibility=hidden",
            "-I", os.path.join(REPO_DIR, "include"), "-o", LIB_PATH] + SOURCES
     if verbose:
         print(" ".join(cmd))
@@ -102,6 +121,8 @@ def lib() -> C.CDLL:
         "vst_error_string": (C.c_char_p, [i]),
         "vst_conv_packed_bytes": (sz, [i, i]),
         "vst_pack_conv": (i, [vp, i, i, vp, vp]),
+        "vst_normalize_block": (i, [vp, vp, vp, vp, vp, i, i, i, vp, vp]),
+        "vst_range_flags": (i, [C.POINTER(C.c_uint), i]),
         "vst_pack_input": (i, [vp, vp, vp, i, i, i, i, vp]),
         "vst_unpack_output": (i, [vp, vp, i, i, i, i, vp]),
         "vst_pack_input_u8": (i, [vp, vp, vp, i, i, i, vp]),
@@ -123,6 +144,11 @@ def lib() -> C.CDLL:
         "vst_cwct_apply": (i, [vp, vp, i, lg, vp, vp, i, vp]),
         "vst_cwct_apply_prec": (i, [vp, vp, i, lg, vp, vp, i, i, vp]),
         "vst_cwct_prefactor": (i, [vp, i, f, vp, vp, vp]),
+        "vst_cwct_stats_f64_workspace_bytes": (sz, [i, lg]),
+        "vst_cwct_stats_f64": (i, [vp, i, lg, vp, i, vp, vp, vp]),
+        "vst_cwct_factor_f64_workspace_bytes": (sz, [i]),
+        "vst_cwct_factor_f64": (i, [vp, C.POINTER(vp), C.POINTER(f), i, f, f, i, vp, vp, vp, vp]),
+        "vst_cwct_apply_f64": (i, [vp, vp, i, lg, vp, vp, i, vp]),
         "vst_label_plan": (i, [vp, lg, vp, lg, vp, vp]),
         "vst_cwct_labels_workspace_bytes": (sz, [i, lg]),
         "vst_cwct_stats_labels": (i, [vp, i, lg, vp, vp, i, vp, vp, vp]),
@@ -175,6 +201,13 @@ def profile_table(run, max_records: int = 4096):
 def kernel_id(cin: int, cout: int, stride: int) -> int:
     """VST_KERNEL_ID of include/vstnet.h."""
     return (cin << 16) | (cout << 4) | stride
+
+
+def range_flags(reset: bool = False) -> int:
+    """fp16 range flags raised on the current device since the last reset (vstnet.h: VST_RANGE_*).  Synchronises the device."""
+    v = C.c_uint(0)
+    check(lib().vst_range_flags(C.byref(v), 1 if reset else 0), "vst_range_flags")
+    return int(v.value)
 
 
 def check(rc: int, what: str) -> None:

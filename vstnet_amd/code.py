@@ -39,6 +39,7 @@ class PackedCode(torch.Tensor):
         # [H*W], its label plan), and the slot count the launches cover
         r._labels = labels
         r._dense = None
+        r._dense_version = 0
         return r
 
     def __repr__(self):
@@ -69,6 +70,14 @@ class PackedCode(torch.Tensor):
     @property
     def pending(self):
         return self._affines is not None or self._labels is not None
+
+    @property
+    def stale(self):
+        """True once somebody has WRITTEN to the materialised values (z.mul_(2), z[:, :, a:b] = v, out= ...): torch applies
+        such edits to the dense tensor — in-place operations on it or on any view of it bump its version counter —, so the
+        packed rows no longer are the code.  Every consumer of the rows (net(z, forward=False), inverse_u8, the cWCT packed
+        routes) then takes the dense values instead, like for any plain tensor."""
+        return self._dense is not None and self._dense._version != self._dense_version
 
     def _need_gpu(self):
         if not self._code.is_cuda:
@@ -121,6 +130,7 @@ class PackedCode(torch.Tensor):
                 _lib.check(L.vst_code_to_z(C.c_void_p(rows.data_ptr()), C.c_void_p(z.data_ptr()), rows.shape[0], H, W,
                                            self._sp, _stream_ptr()), "vst_code_to_z")
             self._dense = z
+            self._dense_version = z._version
         return self._dense
 
     @classmethod

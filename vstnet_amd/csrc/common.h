@@ -53,8 +53,32 @@ __device__ __forceinline__ int reflect_clamp(int v, int n) {
 // resolution, hi = round(x) (saturating at the largest finite fp16), lo = round(x - hi).
 // ---------------------------------------------------------------------------------------------
 #ifdef __HIPCC__
+// fp16 range flags (VST_PREC_F16X2 / VST_PREC_F16X2H): every place that rounds an ACTIVATION to fp16 clamps it to the largest
+// finite fp16 and, if anything was clamped (|x| > 65504, Inf), raises VST_RANGE_SATURATED in this word; vst_pack_conv raises
+// VST_RANGE_WEIGHT for a weight that does not fit.  One word per translation unit (the library is built without relocatable
+// device code), OR-ed together by vst_range_flags (conv.hip).  Read by calibration (RevResNet.check_range), bench.py and tests.
+static __device__ unsigned vst_tu_range_flags;
+__device__ __forceinline__ void vst_note_range(float amax) {
+    if (amax > 65504.f) atomicOr(&vst_tu_range_flags, VST_RANGE_SATURATED);
+}
+#define VST_DEFINE_TU_RANGE(name)                                                                                    \
+    __attribute__((visibility("hidden"))) int name(unsigned* acc, int reset) {                                       \
+        unsigned v = 0;                                                                                              \
+        hipError_t e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(vst_tu_range_flags), sizeof(v));                           \
+        if (e != hipSuccess) return (int)e;                                                                          \
+        *acc |= v;                                                                                                   \
+        if (reset && v) {                                                                                            \
+            const unsigned zero = 0;                                                                                 \
+            e = hipMemcpyToSymbol(HIP_SYMBOL(vst_tu_range_flags), &zero, sizeof(zero));                              \
+            if (e != hipSuccess) return (int)e;                                                                      \
+        }                                                                                                            \
+        return VST_OK;                                                                                               \
+    }
+
 __device__ __forceinline__ void split8_sp(const float (&f)[8], u32x4& hi, u32x4& lo) {
     f16x8 h, l;
+    vst_note_range(fmaxf(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))),
+                         fmaxf(fmaxf(fabsf(f[4]), fabsf(f[5])), fmaxf(fabsf(f[6]), fabsf(f[7])))));
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         h[i] = (_Float16)__builtin_amdgcn_fmed3f(f[i], -65504.f, 65504.f);
@@ -142,7 +166,7 @@ static inline bool vst_is_f16(int precision) { return precision == VST_PREC_F16X
 
 // the split-plane buffer idx (0 = A, 1 = B) inside tmp; layout.hip: gather whose first half goes straight into split planes
 unsigned char* vst3_plane_buffer(void* tmp, int idx, int B, int H, int W);
-extern "C" int vst3_gather_planes(const float* z, unsigned char* s1_planes, float* s2, int B, int H, int W, int sp_steps,
+extern "C" __attribute__((visibility("hidden"))) int vst3_gather_planes(const float* z, unsigned char* s1_planes, float* s2, int B, int H, int W, int sp_steps,
                                   void* stream);
 
 int vst3_presplit(const float* state, unsigned char* planes, int B, int H, int W, void* stream);
@@ -153,7 +177,12 @@ int vst3_apply_code(const float* code, float* out0, float* out1, unsigned char* 
 int vst3_apply_labels_code(const float* code, float* out0, float* out1, unsigned char* planes0, int H, int W,
                            const float* affines, const uint8_t* mask_rows, const void* plan, int max_slots, void* stream);
 
-// internal (not part of the C ABI): input packing with the constant of forward block 0 folded in
-extern "C" int vst_pack_input_k(const float* x, const uint8_t* x_u8, float* s1, float* s2, int B, int C, int H, int W,
+// internal (not part of the C ABI, hidden in the shared library): input packing with the constant of forward block 0 folded in
+#define VST_INTERNAL __attribute__((visibility("hidden")))
+int vst_range_tu_conv(unsigned* acc, int reset);
+int vst_range_tu_conv3(unsigned* acc, int reset);
+int vst_range_tu_layout(unsigned* acc, int reset);
+int vst_range_tu_cwct(unsigned* acc, int reset);
+extern "C" VST_INTERNAL int vst_pack_input_k(const float* x, const uint8_t* x_u8, float* s1, float* s2, int B, int C, int H, int W,
                                 const float* addk, void* stream);
-extern "C" int vst_block0_const(const vst_block_weights* w0, float* k16, void* stream);
+extern "C" VST_INTERNAL int vst_block0_const(const vst_block_weights* w0, float* k16, void* stream);

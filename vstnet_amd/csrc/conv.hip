@@ -117,6 +117,7 @@ __device__ __forceinline__ void split4_f16(const float4 v, uint2& hi, uint2& lo)
     const float f[4] = {v.x, v.y, v.z, v.w};
     typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
     f16x4 h, l;
+    vst_note_range(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float c = __builtin_amdgcn_fmed3f(f[i], -65504.f, 65504.f);
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                 const float r[4] = {acc[m][n][0] + bias[n].x, acc[m][n][1] + bias[n].y, acc[m][n][2] + bias[n].z, acc[m][n][3] + bias[n].w};
                 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
                 f16x4 h;
+                vst_note_range(fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3])));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) h[e] = (_Float16)__builtin_amdgcn_fmed3f(r[e], 0.f, 65504.f);     // ReLU, saturating
                 *(f16x4*)(o16 + ((size_t)oy * a.Wout + ox) * COUT + co) = h;
@@ -1171,7 +1173,22 @@ static const int kBlockChannel[VST_NUM_BLOCKS] = {16, 16, 16, 16, 16, 16, 16, 16
 static const int kBlockStride[VST_NUM_BLOCKS] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1,
                                                  1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
 
+VST_DEFINE_TU_RANGE(vst_range_tu_conv)
+
 extern "C" {
+
+int vst_range_flags(unsigned* flags_host, int reset) {
+    if (!flags_host) return VST_E_ARG;
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return (int)e;
+    unsigned v = 0;
+    if (int rc = vst_range_tu_conv(&v, reset)) return rc;
+    if (int rc = vst_range_tu_conv3(&v, reset)) return rc;
+    if (int rc = vst_range_tu_layout(&v, reset)) return rc;
+    if (int rc = vst_range_tu_cwct(&v, reset)) return rc;
+    *flags_host = v;
+    return VST_OK;
+}
 
 int vst_profile_begin(int kernel_id, int max_records) {
     if ((kernel_id <= 0 && kernel_id != VST_KERNEL_ALL) || max_records <= 0) return VST_E_ARG;

@@ -421,6 +421,8 @@ int vst3_conv_out(const vst_conv_weights* c, const void* in_sp, int in_single, f
     return in_single ? launch_sp<64, 256, true, 1>(a, B, (hipStream_t)stream) : launch_sp<64, 256, true>(a, B, (hipStream_t)stream);
 }
 
+VST_DEFINE_TU_RANGE(vst_range_tu_conv3)
+
 // fp32 half state [B][H/4][W/4][256] -> its split planes
 int vst3_presplit(const float* state, unsigned char* planes, int B, int H, int W, void* stream) {
     hipStream_t st = (hipStream_t)stream;

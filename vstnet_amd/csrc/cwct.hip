@@ -2000,6 +2000,8 @@ int vst3_apply_code(const float* code, float* out0, float* out1, unsigned char* 
     return VST_OK;
 }
 
+VST_DEFINE_TU_RANGE(vst_range_tu_cwct)
+
 extern "C" {
 
 size_t vst_cwct_stats_workspace_bytes(int N, long L) {

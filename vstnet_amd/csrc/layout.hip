@@ -244,6 +244,7 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, int cout, int cin,
         ((__bf16*)(packed + L.f32_bytes))[idx] = hi;
         ((__bf16*)(packed + L.f32_bytes + L.frag_bytes))[idx] = lo;
         ((_Float16*)(packed + L.f16_offset))[idx] = (_Float16)v;      // the 2-term kernels: w rounded to fp16, once
+        if (fabsf(v) > 65504.f) atomicOr(&vst_tu_range_flags, VST_RANGE_WEIGHT);
         if (L.sp_sections) {
             // conv3.hip: the 8 channels of k-group kg are the ones a producer lane holds, {4kg + r, 16 + 4kg + r} of the chunk
             const int cip = (ks / 9) * 32 + (j >> 2) * 16 + kg * 4 + (j & 3);
@@ -255,9 +256,64 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, int cout, int cin,
 }
 
 // ------------------------------------------------------------------------------------------------
+// vst_normalize_block: per-channel power-of-two scales of a residual block's two intermediates (vstnet.h).  One workgroup;
+// the tensors are small (at most 64 x 256 x 9 floats).  Phase 1: s1 from the row norms of W1, applied to W1 / b1 rows and
+// W4 columns; phase 2: s2 from the row norms of the rescaled W4, applied to W4 / b4 rows and W7 columns.
+// s = 2^-round(log2(norm)) through the norm's exponent bits (no transcendental: the same on every device), 1 for a zero row,
+// exponents clamped to +-40.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pow2_scale_of_norm(float sumsq) {
+    const float nrm = sqrtf(sumsq);
+    if (!(nrm > 0.f) || !(nrm < 3.0e38f)) return 1.f;
+    int e;
+    const float m = frexpf(nrm, &e);                 // nrm = m 2^e, m in [0.5, 1): round(log2 nrm) = e if m >= 1/sqrt(2) else e - 1
+    int r = m >= 0.70710678f ? e : e - 1;
+    r = r > 40 ? 40 : (r < -40 ? -40 : r);
+    return ldexpf(1.f, -r);
+}
+
+__global__ __launch_bounds__(256) void normalize_block_kernel(float* __restrict__ w1, float* __restrict__ b1, float* __restrict__ w4,
+                                                              float* __restrict__ b4, float* __restrict__ w7, int cin1, int mid,
+                                                              int cout, float* __restrict__ scales) {
+    __shared__ float sc[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto row_scales = [&](const float* w, int K) {
+        for (int r = wave; r < mid; r += 4) {
+            float acc = 0.f;
+            for (int k = lane; k < K; k += 64) { const float v = w[(size_t)r * K + k]; acc += v * v; }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            if (lane == 0) sc[r] = pow2_scale_of_norm(acc);
+        }
+        __syncthreads();
+    };
+    const int K1 = cin1 * 9, K4 = mid * 9;
+    row_scales(w1, K1);
+    for (int i = tid; i < mid * K1; i += 256) w1[i] *= sc[i / K1];
+    for (int i = tid; i < mid; i += 256) { b1[i] *= sc[i]; if (scales) scales[i] = sc[i]; }
+    for (int i = tid; i < mid * K4; i += 256) w4[i] /= sc[(i / 9) % mid];          // OIHW: input channel = (i / 9) % mid
+    __syncthreads();
+    row_scales(w4, K4);
+    for (int i = tid; i < mid * K4; i += 256) w4[i] *= sc[i / K4];
+    for (int i = tid; i < mid; i += 256) { b4[i] *= sc[i]; if (scales) scales[mid + i] = sc[i]; }
+    for (int i = tid; i < cout * K4; i += 256) w7[i] /= sc[(i / 9) % mid];
+}
+
+VST_DEFINE_TU_RANGE(vst_range_tu_layout)
+
+// ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int vst_version(void) { return 100; }
+int vst_version(void) { return 101; }
+
+int vst_normalize_block(float* w1, float* b1, float* w4, float* b4, float* w7, int c_in1, int c_mid, int c_out, float* scales,
+                        void* stream) {
+    if (!w1 || !b1 || !w4 || !b4 || !w7) return VST_E_ARG;
+    if (c_in1 <= 0 || c_mid <= 0 || c_mid > 64 || c_out <= 0) return VST_E_SHAPE;
+    normalize_block_kernel<<<dim3(1), 256, 0, (hipStream_t)stream>>>(w1, b1, w4, b4, w7, c_in1, c_mid, c_out, scales);
+    VST_RETURN_IF_LAUNCH_FAILED();
+    return VST_OK;
+}
 
 const char* vst_error_string(int code) {
     switch (code) {

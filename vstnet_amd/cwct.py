@@ -7,9 +7,10 @@ public-by-convention helpers).  Differences, all documented in DESIGN.md:
   * the Cholesky-failure path retries with the reference's jitter schedule but never enters pdb;
   * masks must have the feature resolution (the fork does not resize them, cWCT.py:72-73): a
     mismatch raises ValueError instead of indexing out of range;
-  * ``use_double=True`` is rejected (NotImplementedError): the reference's scripts never set it (image_transfer.py:60,
-    video_transfer.py:63, train.py:94 all build ``cWCT()``; in this fork the flag traps into pdb, cWCT.py:36) and the HIP
-    path has no fp64 Cholesky / apply.  What it does in fp64 regardless: the mean / covariance combine;
+  * ``use_double=True`` (cWCT.py:13-16,35-47,66,106,220,238,259; no script of the reference sets it, and in this fork the flag
+    traps into pdb, :36) runs true fp64 two-pass statistics, an fp64 Cholesky / inverse / mix and an fp64-accumulating apply
+    (csrc/cwct64.hip) on the dense NCHW code: a fidelity option — packed codes are materialised first, masked transfers go
+    label by label like the reference's loop.  Without it the mean / covariance combine is fp64, the rest fp32;
   * a batch is factored like the reference's [B,N,N] stack: a sample that needs Cholesky jitter jitters every sample
     (cWCT.py:122-128); ``transfer_with_stats`` / ``transfer_with_plan`` (this repo's cached-style extensions) are per sample.
 All device work goes through libvstnet_hip.so; there is no CPU fallback.
@@ -52,16 +53,12 @@ class cWCT(nn.Module):
         super().__init__()
         # arithmetic of the apply (y = T x + t0): "fp32" = exact fp32 kernels for every N; anything else lets unmasked
         # N >= 64 codes (artistic mode) run on bf16 MFMA with split operands.  Follows RevResNet's knob by default.
-        import os
-        precision = precision or os.environ.get("VST_PRECISION", "f16x2h")
+        precision = precision or _lib.default_precision()
         if precision not in ("fp32", "bf16x3", "f16x2", "f16x2h"):
             raise ValueError("precision must be one of ['bf16x3', 'f16x2', 'f16x2h', 'fp32']")
         self.precision = precision
-        if use_double:
-            raise NotImplementedError("vstnet_amd.cWCT(use_double=True): the HIP path factors and applies in fp32 (statistics "
-                                      "are combined in fp64); an fp64 Cholesky / apply is not implemented")
         self.eps = eps
-        self.use_double = False
+        self.use_double = bool(use_double)
         # upstream CAP-VSTNet resized the label maps to the feature resolution (NEAREST, cWCT.py:191-197); this
         # fork uses them as they are (:72-73), which only fits photorealistic codes.  Opt in to restore it.
         self.resize_masks = resize_masks
@@ -93,6 +90,12 @@ class cWCT(nn.Module):
             raise NotImplementedError(f"HIP cWCT supports N in {_SUPPORTED_N}, got {N}")
         L = _lib.lib()
         out = torch.empty(1 + N + N * N, dtype=torch.float64, device=x2d.device)
+        if self.use_double:
+            ws = self._workspace(L.vst_cwct_stats_f64_workspace_bytes(N, Lp), x2d.device)
+            with torch.cuda.device(x2d.device):
+                _lib.check(L.vst_cwct_stats_f64(_ptr(x2d), N, Lp, _ptr(mask), int(label), _ptr(out), _ptr(ws), _stream_ptr()),
+                           "vst_cwct_stats_f64")
+            return out
         ws = self._workspace(L.vst_cwct_stats_workspace_bytes(N, Lp), x2d.device)
         with torch.cuda.device(x2d.device):
             _lib.check(L.vst_cwct_stats(_ptr(x2d), N, Lp, _ptr(mask), int(label), _ptr(out), _ptr(ws), _stream_ptr()),
@@ -112,10 +115,15 @@ class cWCT(nn.Module):
                        "vst_cwct_stats_code")
         return out
 
+    def _is_packed(self, x):
+        if self.use_double:
+            return False
+        return self._is_packed_code(x)
+
     @staticmethod
-    def _is_packed(x):
-        """A photorealistic code still in the coupling blocks' layout, no cWCT pending on it (code.py)."""
-        return isinstance(x, PackedCode) and not x.pending
+    def _is_packed_code(x):
+        """A code still in the coupling blocks' layout, no cWCT pending on it (code.py); use_double works on dense codes."""
+        return isinstance(x, PackedCode) and not x.pending and not x.stale
 
     def factor(self, content_stats, style_stats_list, alphas, alpha_c, N, min_tries=None):
         """{T, t0} with T = (sum_i a_i chol(Cs_i) [blended with chol(Cc)]) * chol(Cc)^-1.  min_tries: device int32
@@ -123,10 +131,18 @@ class cWCT(nn.Module):
         L = _lib.lib()
         n = len(style_stats_list)
         dev = content_stats.device
-        affine = torch.empty(N * N + N, dtype=torch.float32, device=dev)
         info = torch.zeros(2 + n, dtype=torch.int32, device=dev) if min_tries is None else min_tries.clone()
         ptrs = (C.c_void_p * n)(*[s.data_ptr() for s in style_stats_list])
         al = (C.c_float * n)(*[float(a) for a in alphas])
+        if self.use_double:                     # fp64 Cholesky / inverse / mix: a DOUBLE affine record
+            affine = torch.empty(N * N + N, dtype=torch.float64, device=dev)
+            fws = torch.empty(L.vst_cwct_factor_f64_workspace_bytes(N), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(L.vst_cwct_factor_f64(_ptr(content_stats), ptrs, al, n, float(alpha_c), float(self.eps), N,
+                                                 _ptr(affine), _ptr(info), _ptr(fws), _stream_ptr()), "vst_cwct_factor_f64")
+            self.last_info = info
+            return affine
+        affine = torch.empty(N * N + N, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(L.vst_cwct_factor(_ptr(content_stats), ptrs, al, n, float(alpha_c), float(self.eps), N,
                                          _ptr(affine), _ptr(info), _stream_ptr()), "vst_cwct_factor")
@@ -137,6 +153,11 @@ class cWCT(nn.Module):
         N, Lp = x2d.shape
         if out is None:
             out = torch.empty_like(x2d)
+        if self.use_double:
+            with torch.cuda.device(x2d.device):
+                _lib.check(_lib.lib().vst_cwct_apply_f64(_ptr(x2d), _ptr(out), N, Lp, _ptr(affine), _ptr(mask), int(label),
+                                                         _stream_ptr()), "vst_cwct_apply_f64")
+            return out
         with torch.cuda.device(x2d.device):
             prec = {"fp32": _lib.PREC_FP32, "bf16x3": _lib.PREC_BF16X3, "f16x2": _lib.PREC_F16X2, "f16x2h": _lib.PREC_F16X2H}[self.precision]
             _lib.check(_lib.lib().vst_cwct_apply_prec(_ptr(x2d), _ptr(out), N, Lp, _ptr(affine), _ptr(mask), int(label),
@@ -171,7 +192,8 @@ class cWCT(nn.Module):
         styles = []
         for sf in styl_feat_list:
             assert sf.shape[0] == B and sf.shape[1] == N
-            styles.append(sf if isinstance(sf, PackedCode) else self._prep(sf).reshape(B, N, -1))
+            styles.append(sf if isinstance(sf, PackedCode) and not sf.stale and not self.use_double
+                          else self._prep(sf).reshape(B, N, -1))
         one = lambda t, b: self.stats_code(t, b) if isinstance(t, PackedCode) else self.stats(t[b])      # noqa: E731
         stats = [(one(content_feat, b) if packed else self.stats(c[b]), [one(s, b) for s in styles]) for b in range(B)]
         affines, infos = [], []
@@ -197,11 +219,14 @@ class cWCT(nn.Module):
         re-encodes and re-factors the style for every frame (video_transfer.py:195); a video loop can
         compute this once per style and call transfer_with_stats per frame."""
         B, N = style_feat.shape[:2]
-        packed = isinstance(style_feat, PackedCode)
+        packed = isinstance(style_feat, PackedCode) and not style_feat.stale and not self.use_double
         s = None if packed else self._prep(style_feat).reshape(B, N, -1)
         out = []
         for b in range(B):
             st = self.stats_code(style_feat, b) if packed else self.stats(s[b])
+            if self.use_double:                      # (the prefactored record stores an fp32 factor)
+                out.append(st)
+                continue
             info = torch.zeros(1, dtype=torch.int32, device=st.device)
             with torch.cuda.device(st.device):       # Cholesky once per style, in place
                 _lib.check(_lib.lib().vst_cwct_prefactor(_ptr(st), N, float(self.eps), _ptr(st), _ptr(info), _stream_ptr()),
@@ -229,7 +254,8 @@ class cWCT(nn.Module):
 
     def _transfer_seg(self, content_feat, style_feat, cmask, smask):
         """models/cWCT.py:49-109."""
-        if content_feat.shape[1] == 16:       # no matrix-core form at N = 16: one statistics + apply pass per label
+        if content_feat.shape[1] == 16 or self.use_double:
+            # no matrix-core form at N = 16, no single-pass fp64 form: one statistics + apply pass per label (cWCT.py:83-103)
             return self._transfer_seg_per_label(content_feat, style_feat, cmask, smask)
         plan = self.plan_masks(cmask, smask, content_feat.shape, style_feat.shape, content_feat.device)
         return self.transfer_with_plan(content_feat, style_feat, plan)
@@ -291,7 +317,26 @@ class cWCT(nn.Module):
         """Read the slot counts back once (one synchronisation) so that later launches cover only the slots in use — worth
         it for a plan that is reused over a clip."""
         plan.max_slots = max(1, max(len(self.plan_info(plan, b)[0]) for b in range(len(plan.tables))))
+        self._ensure_mask_rows(plan)
         return plan
+
+    def _ensure_mask_rows(self, plan):
+        """The content label maps in a PackedCode's row order, for plans the packed masked route can take (photorealistic
+        codes, at most 8 slots).  Built HERE, once, and completed before returning: the plan is then shared by frames in
+        flight on several streams (FramePipeline, bench.py), none of which may meet a half-written map."""
+        B, N, cH, cW = plan.shapes[0]
+        if plan.cm_rows is not None or N != 32 or not (1 <= int(plan.max_slots) <= 8):
+            return
+        L = _lib.lib()
+        dev = plan.cm[0].device
+        rows_all = []
+        with torch.cuda.device(dev):
+            for b in range(B):
+                rows = torch.empty_like(plan.cm[b])
+                _lib.check(L.vst_mask_to_code(_ptr(plan.cm[b]), _ptr(rows), cH, cW, _stream_ptr()), "vst_mask_to_code")
+                rows_all.append(rows)
+            torch.cuda.current_stream(dev).synchronize()
+        plan.cm_rows = rows_all
 
     def _stats_labels(self, x2d, mask, table, max_slots):
         N, Lp = x2d.shape
@@ -319,6 +364,9 @@ class cWCT(nn.Module):
         B, N, cH, cW = content_feat.shape
         if tuple(content_feat.shape) != plan.shapes[0]:
             raise ValueError(f"plan was made for a content code of shape {plan.shapes[0]}, got {tuple(content_feat.shape)}")
+        if self.use_double:
+            raise NotImplementedError("transfer_with_plan (this repo's cached-mask extension) has no fp64 form: with "
+                                      "use_double=True call transfer(content, style, cmask, smask)")
         if self._is_packed(content_feat) and content_feat.sp_steps == 2 and 1 <= int(plan.max_slots) <= 8:
             return self._transfer_with_plan_packed(content_feat, style_feat, plan)
         in_dtype = content_feat.dtype
@@ -354,13 +402,7 @@ class cWCT(nn.Module):
         L = _lib.lib()
         ms = int(plan.max_slots)
         dev = content.packed.device
-        if plan.cm_rows is None:
-            plan.cm_rows = []
-            for b in range(B):
-                rows = torch.empty_like(plan.cm[b])
-                with torch.cuda.device(dev):
-                    _lib.check(L.vst_mask_to_code(_ptr(plan.cm[b]), _ptr(rows), cH, cW, _stream_ptr()), "vst_mask_to_code")
-                plan.cm_rows.append(rows)
+        self._ensure_mask_rows(plan)          # (a plan whose max_slots was set by hand: built and completed now)
         s = None
         if plan.style is None:
             if style_feat is None or tuple(style_feat.shape) != plan.shapes[1]:

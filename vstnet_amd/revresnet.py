@@ -19,7 +19,7 @@ from . import _lib
 from .code import PackedCode
 from .synth import STACK, CONV_IDX
 
-_PRECISIONS = {"bf16x3": _lib.PREC_BF16X3, "fp32": _lib.PREC_FP32, "f16x2": _lib.PREC_F16X2, "f16x2h": _lib.PREC_F16X2H}
+_PRECISIONS = _lib.PRECISIONS
 
 
 def _stream_ptr() -> C.c_void_p:
@@ -78,7 +78,7 @@ class RevResNet(nn.Module):
         self.sp_steps = sp_steps
         self.stack = nn.ModuleList([residual_block(ch, stride, mult=mult, kernel=kernel) for stride, ch in STACK])
         self.channel_reduction = channel_reduction(nChannels[-1], hidden_dim, sp_steps=sp_steps, kernel=kernel)
-        precision = precision or os.environ.get("VST_PRECISION", "f16x2h")
+        precision = precision or _lib.default_precision()
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
         self.precision = precision
@@ -86,6 +86,10 @@ class RevResNet(nn.Module):
         # coupling blocks' own layout for cWCT and the inverse pass) where the passes run image by image anyway (_use_packed);
         # "always": for every batch; False or VST_PACKED_CODE=0: always plain NCHW
         self.packed_code = os.environ.get("VST_PACKED_CODE", "1") != "0"
+        # exponent normalisation of h1 / h2 at pack time (function-preserving, exact in fp32; see vst_normalize_block)
+        self.normalize_intermediates = os.environ.get("VST_NORMALIZE", "1") != "0"
+        # fp16 modes: probe pass + range flags after every (re)pack (see _calibrate)
+        self.calibrate_on_load = os.environ.get("VST_CALIBRATE", "1") != "0"
         self._packed = None          # (device, blob tensor, bias tensors, NetWeights struct, parameter versions)
         self._workspace = None
         # a PARENT module's load_state_dict never calls this module's load_state_dict: invalidate through the hook as well
@@ -109,11 +113,15 @@ class RevResNet(nn.Module):
         return out
 
     def refresh_weights(self):
-        """Call after editing parameters in place (the packed copies are rebuilt on the next call)."""
+        """Drop the packed weight copies (rebuilt on the next call).  Needed only after edits the cache key cannot see:
+        writes through ``param.data`` (``p.data.copy_(...)``); in-place ops on the parameter itself, ``load_state_dict``
+        and ``.to()`` are noticed automatically."""
         self._invalidate()
 
     def _param_versions(self, convs):
-        # in-place edits (param.data.copy_, optimizer.step, load_state_dict's copy_) bump a tensor's _version
+        # in-place edits of the PARAMETER (p.copy_ / p.add_ under no_grad, optimizer.step, load_state_dict's copy_) bump its
+        # _version.  Edits through `p.data` do NOT (p.data is a separate tensor object with its own counter and the same
+        # storage): after p.data.copy_(...) call refresh_weights().
         return tuple(p._version for c in convs for p in (c.weight, c.bias)) + tuple(p.data_ptr() for c in convs for p in (c.weight, c.bias))
 
     def _ensure_packed(self, device):
@@ -135,11 +143,22 @@ class RevResNet(nn.Module):
         net = _lib.NetWeights()
         with torch.cuda.device(device):
             st = _stream_ptr()
-            for k, c in enumerate(convs):
+            wb = []
+            for c in convs:
                 if c.weight.device != device:
                     raise RuntimeError(f"RevResNet parameters live on {c.weight.device}, input on {device}: call .to(device)")
-                w = c.weight.detach().to(torch.float32).contiguous()
-                b = c.bias.detach().to(torch.float32).clone()       # a copy: the packed weights and their bias age together
+                # copies: the packed weights and their bias age together, and the normalisation below works in place
+                wb.append((c.weight.detach().to(torch.float32).clone(memory_format=torch.contiguous_format),
+                           c.bias.detach().to(torch.float32).clone()))
+            if self.normalize_intermediates:     # vstnet.h vst_normalize_block: h1 / h2 channels to unit weight-row scale
+                for j in range(0, len(convs), 3):
+                    (w1, b1), (w4, b4), (w7, _) = wb[j:j + 3]
+                    _lib.check(L.vst_normalize_block(C.c_void_p(w1.data_ptr()), C.c_void_p(b1.data_ptr()), C.c_void_p(w4.data_ptr()),
+                                                     C.c_void_p(b4.data_ptr()), C.c_void_p(w7.data_ptr()), convs[j].in_channels,
+                                                     convs[j].out_channels, convs[j + 2].out_channels, C.c_void_p(0), st),
+                               "vst_normalize_block")
+            for k, c in enumerate(convs):
+                w, b = wb[k]
                 biases.append((w, b))
                 _lib.check(L.vst_pack_conv(C.c_void_p(w.data_ptr()), c.out_channels, c.in_channels,
                                            C.c_void_p(blob.data_ptr() + int(offsets[k])), st), "vst_pack_conv")
@@ -149,7 +168,43 @@ class RevResNet(nn.Module):
             # one-off: the packed blob may be used from any stream afterwards (frames in flight on several streams)
             torch.cuda.current_stream(device).synchronize()
         self._packed = (device, blob, biases, net, versions)
+        if self.precision in ("f16x2", "f16x2h") and self.calibrate_on_load:
+            self._calibrate(device)
         return net
+
+    # ------------------------------------------------------------------ fp16 range (the narrowed modes only)
+    def check_range(self, sample=None):
+        """One forward + inverse pass of ``sample`` ([B,3,H,W] in the caller's value range; default: a seeded uniform [0,1)
+        64x64 frame) and the fp16 range flags it raised on the device (vstnet.h VST_RANGE_*: 1 = an activation beyond
+        +-65504 was clamped, 2 = a weight beyond fp16 range).  0 = the fp16 modes saw nothing out of range.  The flags are
+        device-wide and sticky; this call clears them before and after (it synchronises the device: a calibration call)."""
+        from .synth import synthetic_frames
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("vstnet_amd.RevResNet runs on ROCm devices only (no CPU fallback): move the module to 'cuda'")
+        x = synthetic_frames(1, 64, 64, seed=12345).to(dev) if sample is None else sample.to(dev)
+        with torch.cuda.device(dev), torch.no_grad():
+            _lib.range_flags(reset=True)
+            z = self(x)
+            self(z, forward=False)
+            return _lib.range_flags(reset=True)
+
+    def _calibrate(self, device):
+        """Load-time check of the fp16 modes (after every repack): the packed fp16 weights must be finite and a probe frame
+        must pass without saturating an fp16 operand; otherwise the mode is unusable on this checkpoint and says so."""
+        with torch.cuda.device(device):
+            flags = _lib.range_flags(reset=True) & _lib.RANGE_WEIGHT       # raised by vst_pack_conv just now
+        if not flags:
+            flags = self.check_range()
+        if flags:
+            self._packed = None
+            what = []
+            if flags & _lib.RANGE_WEIGHT:
+                what.append("a conv weight is beyond the fp16 range")
+            if flags & _lib.RANGE_SATURATED:
+                what.append("an activation of the probe frame saturated at +-65504")
+            raise RuntimeError(f"precision='{self.precision}' cannot represent this checkpoint ({'; '.join(what)}): "
+                               "use precision='bf16x3'")
 
     def _get_workspace(self, nbytes, device):
         """Pass workspace, one per (device, stream): frames in flight on different streams must not share state."""
@@ -201,7 +256,7 @@ class RevResNet(nn.Module):
     def _inverse(self, z):
         """models/RevResNet.py:225-239."""
         s = self.sp_steps
-        if isinstance(z, PackedCode) and z.sp_steps == s:
+        if isinstance(z, PackedCode) and z.sp_steps == s and not z.stale:
             return self._decode_packed(z, u8=False)
         z = self._check(z, 32 if s == 2 else 128, "RevResNet inverse input")
         B = z.shape[0]
@@ -300,7 +355,7 @@ class RevResNet(nn.Module):
         """Decode a code to uint8 HWC frames with the reference's quantisation: mul(255).clamp(0,255).byte()
         (truncation; image_transfer.py:217-218, video_transfer.py:212) fused into the last boundary kernel."""
         s = self.sp_steps
-        if isinstance(z, PackedCode) and z.sp_steps == s:
+        if isinstance(z, PackedCode) and z.sp_steps == s and not z.stale:
             return self._decode_packed(z, u8=True)
         z = self._check(z, 32 if s == 2 else 128, "RevResNet inverse input")
         B = z.shape[0]

@@ -20,6 +20,52 @@ def shard_range(n_frames: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def rank_threads(world: int) -> int:
+    """CPU threads one rank of `world` may use on this host: the ranks of a node share its cores, and N ranks x torch's
+    default intra-op pool (one thread per core each) is the oversubscription that throttled the feeding thread once
+    (vstnet_amd/pipeline.py)."""
+    return max(1, (os.cpu_count() or 1) // max(1, world))
+
+
+def rank_environment(rank: int, world: int, port: int | None = None, visible_device: bool = False) -> dict:
+    """Environment of child `rank` of a self-launched node-local job: the torch.distributed.run variables (when a
+    rendezvous port is given), a per-rank CPU thread cap, and — `visible_device` — HIP_VISIBLE_DEVICES so that the child
+    sees exactly its own GPU as device 0 (children that need no rendezvous, e.g. video shards)."""
+    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    n = str(rank_threads(world))
+    for k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+        env.setdefault(k, n)
+    if port is not None:
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if visible_device:
+        env["HIP_VISIBLE_DEVICES"] = str(rank)
+        env["LOCAL_RANK"] = "0"
+    return env
+
+
+def launch_children(commands, environments, poll_s: float = 0.05) -> int:
+    """Start one child process per (command, environment) pair and wait for all of them.  The caller has not touched a GPU
+    (children do).  The first child that fails terminates the others — exactly the processes started here — and its exit
+    code is returned; 0 if every child succeeded.  No re-exec, no retry."""
+    import subprocess
+    procs = [subprocess.Popen(list(cmd), env=env) for cmd, env in zip(commands, environments)]
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in pending:
+                    other.terminate()
+        time.sleep(poll_s)
+    return rc
+
+
 def dist_env():
     """(rank, local_rank, world) from the torch.distributed.run environment (1-process defaults)."""
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
