@@ -129,6 +129,37 @@ def test_packed_code_host_side():
         t.materialize()
 
 
+def test_packed_code_notices_writes():
+    """in-place edits of a PackedCode (direct, through a view, out=) mark the packed rows stale; reads do not.
+    (Host logic only: materialize() is replaced by a CPU stand-in; the GPU side is test_packed_code_inplace_edits_are_not_lost.)"""
+    from vstnet_amd.code import PackedCode
+
+    class P(PackedCode):
+        def materialize(self):
+            if self._dense is None:
+                self._dense = torch.arange(2 * 32 * 16, dtype=torch.float32).reshape(2, 32, 4, 4).clone()
+            return self._dense
+    rows = torch.zeros(2, 32 * 16)
+    with torch.no_grad():
+        z = P(rows, 4, 4)
+        _ = z + 1.0, z[:, 3:5].sum(), z.reshape(2, -1).mean()
+        assert not z.stale
+        z.mul_(2.0)
+        assert z.stale and float(z.materialize()[0, 0, 0, 1]) == 2.0
+        z = P(rows, 4, 4)
+        z[:, :, 1:3] = 0.5
+        assert z.stale and float(z.materialize()[0, 0, 1, 0]) == 0.5
+        z = P(rows, 4, 4)
+        v = z[:, 1]
+        assert not z.stale
+        v.add_(1.0)
+        assert z.stale
+        z = P(rows, 4, 4)
+        torch.add(z, 1.0, out=z)
+        assert z.stale
+        assert not P(rows, 4, 4).with_affines(torch.zeros(2, 1056)).stale
+
+
 def test_product_does_not_import_oracle():
     for root, _, files in os.walk(os.path.join(REPO, "vstnet_amd")):
         for f in files:

@@ -39,7 +39,7 @@ class PackedCode(torch.Tensor):
         # [H*W], its label plan), and the slot count the launches cover
         r._labels = labels
         r._dense = None
-        r._dense_version = 0
+        r._version0 = r._version  # of this wrapper: torch bumps it on every in-place op on the code or on a view of it
         return r
 
     def __repr__(self):
@@ -73,11 +73,12 @@ class PackedCode(torch.Tensor):
 
     @property
     def stale(self):
-        """True once somebody has WRITTEN to the materialised values (z.mul_(2), z[:, :, a:b] = v, out= ...): torch applies
-        such edits to the dense tensor — in-place operations on it or on any view of it bump its version counter —, so the
-        packed rows no longer are the code.  Every consumer of the rows (net(z, forward=False), inverse_u8, the cWCT packed
-        routes) then takes the dense values instead, like for any plain tensor."""
-        return self._dense is not None and self._dense._version != self._dense_version
+        """True once somebody has WRITTEN to the code (z.mul_(2), z[:, :, a:b] = v, v = z[:, 1]; v.add_(1), out=z ...).  Such
+        edits land in the materialised dense tensor (__torch_dispatch__ runs the op on it), and torch's in-place / view
+        tracking bumps THIS tensor's version counter for them — also for writes through views, which share it — so the packed
+        rows no longer are the code.  Every consumer of the rows (net(z, forward=False), inverse_u8, the cWCT packed routes)
+        then takes the dense values instead, like for any plain tensor."""
+        return self._version != self._version0
 
     def _need_gpu(self):
         if not self._code.is_cuda:
@@ -130,7 +131,6 @@ class PackedCode(torch.Tensor):
                 _lib.check(L.vst_code_to_z(C.c_void_p(rows.data_ptr()), C.c_void_p(z.data_ptr()), rows.shape[0], H, W,
                                            self._sp, _stream_ptr()), "vst_code_to_z")
             self._dense = z
-            self._dense_version = z._version
         return self._dense
 
     @classmethod
