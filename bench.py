@@ -59,7 +59,7 @@ def parse_args(argv=None):
                     "per-pixel random labels (the worst case for any per-label tile skipping)")
     ap.add_argument("--mode", default="photo", choices=["photo", "art"])
     ap.add_argument("--frames-per-gpu", type=int, default=1)
-    ap.add_argument("--precision", default=None, choices=["f16x2", "f16x2h", "bf16x3", "fp32"],
+    ap.add_argument("--precision", default=None, choices=["f16x2", "f16x2h", "bf16x3", "fp32", "auto"],
                     help="conv arithmetic of the timed region (`value`); default: the library's default = bf16x3, the fp32-class "
                          "mode.  The fp16 modes are opt-in and reported per mode under `modes` with their own parity figures")
     ap.add_argument("--recompute-style", action="store_true", help="re-encode + re-factor the style every frame "
@@ -191,6 +191,7 @@ def main():
                                           device=dev if use_nccl else "cpu", return_all=True)
         assert torch.isfinite(step()).all()
         torch.cuda.synchronize()
+        args.effective_precision = net.resolved_precision
 
         # ---- extras, all outside the timed region ----------------------------------------------------------------------
         extras = {}
@@ -216,7 +217,7 @@ def main():
         mode_rates, mode_out = {}, {}
         if rank == 0 and world == 1 and not args.no_extras and not args.masked and not args.recompute_style:
             n_alt = max(2, min(args.steps, 60))
-            for p_alt in ("bf16x3", "f16x2", "f16x2h"):
+            for p_alt in ("bf16x3", "f16x2", "f16x2h", "auto"):
                 if p_alt == args.precision:
                     net_a, s_alt = net, s_stats
                 else:
@@ -245,6 +246,8 @@ def main():
                 t_alt = timed_steps(step_alt, n_alt, 3, torch.cuda.synchronize, 1)
                 t_seq = timed_steps(step_seq, n_alt, 2, torch.cuda.synchronize, 1)
                 mode_rates[p_alt] = (fpg * n_alt / t_alt, fpg * n_alt / t_seq)
+                if p_alt == "auto":
+                    extras["auto_calibration"] = net_a.calibration
                 if not args.no_cpu_baseline:
                     keep = {}
                     frame_alt(keep)
@@ -275,7 +278,8 @@ def main():
                            "fp16; conv inputs that cross HBM (h1, h2, the state as the 256-channel blocks' first conv reads it) are "
                            "fp16 tensors: 1 MFMA per product; operands split in-kernel from the f32 state: fp16 hi+lo, 2 MFMAs (opt-in mode)",
                  "bf16x3": "f32 state / f32 accumulate; bf16 3-term split MFMA (a_hi w_hi + a_lo w_hi + a_hi w_lo): fp32-class, "
-                           "3e-6 of the reference; the library default", "fp32": "f32"}[args.precision]
+                           "3e-6 of the reference; the library default", "fp32": "f32",
+                 "auto": "self-calibrated: one of f16x2h / f16x2 / bf16x3, see auto_calibration"}[args.precision]
     rec = {
         "metric": "stylized frames/sec at 1024x1024 (1/2/4/8 GPU) + % HBM roofline",
         "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -284,7 +288,8 @@ def main():
         "config": {"workload": f"{'photorealistic' if args.mode == 'photo' else 'artistic'} {Wf}x{Hf} frame: RevResNet "
                    f"forward + cWCT ({str(args.masked) + '-label ' + args.mask_kind + ' masks, ' if args.masked else ''}{'style re-encoded per frame' if args.recompute_style else 'style statistics cached'})"
                    " + RevResNet inverse", "frames_per_gpu": fpg, "sharding": f"{world} ranks x {fpg} frame(s), no collective",
-                   "weights": "synthetic seed 1234", "frames_in_flight": max(1, args.streams), "precision": args.precision},
+                   "weights": "synthetic seed 1234", "frames_in_flight": max(1, args.streams), "precision": args.precision,
+                   "resolved_precision": net.resolved_precision},
         "per_rank": {"frames_per_s": per_rank_fps, "min": min(per_rank_fps), "max": max(per_rank_fps)},
         "frame_hbm_roofline": {"bound": "hbm", "algorithmic_bytes_per_frame": frame_bytes,
                                "achieved": round(frame_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -308,6 +313,10 @@ def main():
                                 "parity_* (added by the CPU leg) = this run's frame 0 vs the oracle frame; `value` is the mode "
                                 f"named in config.precision ({args.precision})")
         rec["sequential_frames_per_s"] = rec["modes"].get(args.precision, {}).get("sequential_frames_per_s")
+        if "auto" in rec["modes"] and "auto_calibration" in rec:
+            rec["modes"]["auto"]["resolved"] = rec["auto_calibration"]["chosen"]
+            rec["modes"]["auto"]["what"] = ("precision='auto' (opt-in): the fastest mode whose probe stylisation on this checkpoint "
+                                            "stays within auto_calibration.tolerance of bf16x3 on the device")
 
     if args.host_pipeline > 0 and not args.masked and fpg == 1:
         # PCIe-inclusive: uint8 frames in pageable host memory -> pinned ring -> H2D -> encode/cWCT/decode -> D2H -> host
@@ -344,7 +353,8 @@ def roofline_from_table(table, n_frames, fpg, H, W, args, _lib):
     """Per-launch roofline of the conv class with the largest total time, and a per-stage summary, from the HIP-event
     table of `n_frames` frames run one at a time (ms are per frame below)."""
     px = fpg * H * W                                   # full-resolution pixels per frame batch
-    f16 = "h" if args.precision == "f16x2h" else args.precision == "f16x2"      # truthy for both fp16 modes
+    prec = getattr(args, "effective_precision", None) or args.precision
+    f16 = "h" if prec == "f16x2h" else prec == "f16x2"      # truthy for both fp16 modes
     per = {}                                           # (cin, cout, stride) -> (ms per frame, launches per frame)
     for kid, (ms, cnt) in table.items():
         if kid >= 65536:
@@ -368,7 +378,7 @@ def roofline_from_table(table, n_frames, fpg, H, W, args, _lib):
     pmc_path = os.path.join(REPO, "profiles", PMC_FILE)
     if os.path.exists(pmc_path) and (H, W) == (1024, 1024) and fpg == 1 and args.mode == "photo":
         pmc = json.load(open(pmc_path))
-        if pmc.get("precision", "f16x2h") == args.precision:
+        if pmc.get("precision", "f16x2h") == prec:
             names = [f"<{cin}, {cout},", f"<{cin},{cout},"]
             hit = [v for n, v in pmc["kernels"].items() if any(t in n for t in names) and ("conv_sp" in n or "conv_pipe" in n or "conv_mfma" in n)]
             traffic = hit[0]["hbm_bytes_per_launch"] if hit else None

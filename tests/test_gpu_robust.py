@@ -122,6 +122,34 @@ def test_ill_conditioned_code(mode, precision, span):
         assert max(e_zc, e_zcs, e_sty) <= BUDGET and e_ch <= BUDGET_CHANNEL
 
 
+@pytest.mark.parametrize("span,expect", [(None, ("f16x2h",)), (10.0, ("f16x2h", "f16x2")), (1e3, ("bf16x3",))])
+def test_auto_precision_picks_a_mode_that_holds_the_budget(span, expect):
+    """precision='auto': at (re)pack time a probe stylisation per candidate mode is compared ON THE DEVICE with bf16x3; the
+    fastest mode within a quarter of the budget is taken.  On the friendly checkpoint that is f16x2h, on the ill-conditioned
+    one bf16x3 — and whatever it picks must hold the 1e-3 budget against the ORACLE on frames other than the probe."""
+    sd = synthetic_state_dict(1234, 16, 2)
+    if span is not None:
+        sd = ramp_state_dict(sd, span, 32)
+    net, _ = _net(sd, "photo", "auto")
+    xc, xs = synthetic_frames(1, 96, 96, seed=0), synthetic_frames(1, 96, 96, seed=1)
+    ref = _oracle(("ill", "photo", span) if span is not None else ("friendly",), xc, xs, sd, 2)
+    got = _stylize_gpu(net, xc, xs)
+    assert net.resolved_precision in expect, (net.resolved_precision, net.calibration)
+    errs = [rel_l2(got[i], ref[i]) for i in (0, 2, 3)]
+    _record("auto_precision", span=span, chosen=net.resolved_precision, zc=errs[0], zcs=errs[1], stylized=errs[2],
+            calibration=net.calibration)
+    assert max(errs) <= BUDGET and worst_channel(got[2], ref[2]) <= BUDGET_CHANNEL, (net.resolved_precision, errs)
+    rec = net.calibrate(xc, xs)                                   # the caller's own frames: same verdict here
+    assert rec["chosen"] in expect and net.resolved_precision == rec["chosen"]
+    # a repack (new weights) decides again
+    net.load_state_dict(ramp_state_dict(synthetic_state_dict(1234, 16, 2), 1e3, 32))
+    net(xc.cuda())
+    assert net.resolved_precision == "bf16x3"
+    fixed, _ = _net(sd, "photo", "bf16x3")
+    with pytest.raises(RuntimeError):
+        fixed.calibrate()
+
+
 # ------------------------------------------------------------------------------------------- (b) scales
 @pytest.mark.parametrize("f1,f2", [(1e3, 1e-3), (1e-3, 1e3), (2.0 ** 12, 2.0 ** 12)])
 @pytest.mark.parametrize("precision", MODES)

@@ -54,8 +54,10 @@ class cWCT(nn.Module):
         # arithmetic of the apply (y = T x + t0): "fp32" = exact fp32 kernels for every N; anything else lets unmasked
         # N >= 64 codes (artistic mode) run on bf16 MFMA with split operands.  Follows RevResNet's knob by default.
         precision = precision or _lib.default_precision()
+        if precision == "auto":               # (RevResNet's self-calibrating mode: nothing to decide here)
+            precision = "bf16x3"
         if precision not in ("fp32", "bf16x3", "f16x2", "f16x2h"):
-            raise ValueError("precision must be one of ['bf16x3', 'f16x2', 'f16x2h', 'fp32']")
+            raise ValueError("precision must be one of ['auto', 'bf16x3', 'f16x2', 'f16x2h', 'fp32']")
         self.precision = precision
         self.eps = eps
         self.use_double = bool(use_double)

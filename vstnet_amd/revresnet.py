@@ -79,9 +79,15 @@ class RevResNet(nn.Module):
         self.stack = nn.ModuleList([residual_block(ch, stride, mult=mult, kernel=kernel) for stride, ch in STACK])
         self.channel_reduction = channel_reduction(nChannels[-1], hidden_dim, sp_steps=sp_steps, kernel=kernel)
         precision = precision or _lib.default_precision()
-        if precision not in _PRECISIONS:
-            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+        if precision not in _PRECISIONS and precision != "auto":
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS) + ['auto']}")
+        # "auto": the fastest of f16x2h / f16x2 / bf16x3 that a probe stylisation on THIS checkpoint keeps within
+        # `auto_tolerance` of the bf16x3 result (see _auto_select); decided after every (re)pack, readable as
+        # resolved_precision / calibration
         self.precision = precision
+        self.auto_tolerance = 2.5e-4
+        self.resolved_precision = None if precision == "auto" else precision
+        self.calibration = None
         # photorealistic mode: net(x) returns the code as a PackedCode (code.py: [B,32,H,W] to every caller, kept in the
         # coupling blocks' own layout for cWCT and the inverse pass) where the passes run image by image anyway (_use_packed);
         # "always": for every batch; False or VST_PACKED_CODE=0: always plain NCHW
@@ -168,9 +174,69 @@ class RevResNet(nn.Module):
             # one-off: the packed blob may be used from any stream afterwards (frames in flight on several streams)
             torch.cuda.current_stream(device).synchronize()
         self._packed = (device, blob, biases, net, versions)
-        if self.precision in ("f16x2", "f16x2h") and self.calibrate_on_load:
+        if self.precision == "auto":
+            self._auto_select(device)
+        elif self.precision in ("f16x2", "f16x2h") and self.calibrate_on_load:
             self._calibrate(device)
         return net
+
+    def _prec(self):
+        """C-ABI code of the arithmetic the passes run in (the resolved mode under precision='auto')."""
+        return _PRECISIONS[self.resolved_precision or "bf16x3"]
+
+    # ------------------------------------------------------------------ precision="auto"
+    def calibrate(self, content=None, style=None):
+        """precision='auto': (re)decide the arithmetic mode on sample frames of the caller's own data ([1,3,H,W] in the
+        caller's value range; default: two seeded uniform [0,1) 128x128 frames).  Returns the calibration record."""
+        if self.precision != "auto":
+            raise RuntimeError("calibrate() chooses a mode for precision='auto'; this module's precision is fixed")
+        dev = next(self.parameters()).device
+        self._ensure_packed(dev)
+        return self._auto_select(dev, content, style)
+
+    def _auto_select(self, device, content=None, style=None):
+        """One probe stylisation (encode content + style, cWCT, decode) per candidate mode, compared ON THE DEVICE with the same
+        probe in bf16x3, the fp32-class mode: a candidate is taken if its codes and its stylised frame are within
+        `auto_tolerance` (rel-L2; default 2.5e-4, a quarter of the 1e-3 budget) and the worst channel of z_cs within 10x that,
+        and no fp16 range flag was raised.  Fastest first: f16x2h, f16x2; otherwise bf16x3.  The narrowed modes' error is a
+        property of the checkpoint (11-bit weights are a fixed perturbation of the model; how much the model amplifies it is
+        what this measures), so one probe per (re)pack decides; calibrate() repeats it on the caller's own frames."""
+        from .cwct import cWCT
+        from .synth import synthetic_frames
+        xc = synthetic_frames(1, 128, 128, seed=4242).to(device) if content is None else content.to(device)
+        xs = synthetic_frames(1, 128, 128, seed=4243).to(device) if style is None else style.to(device)
+        cw = cWCT(precision="bf16x3")
+        rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-300))       # noqa: E731
+
+        def probe(mode):
+            self.resolved_precision = mode
+            _lib.range_flags(reset=True)
+            zc = self(xc)
+            zcs = cw.transfer(zc, self(xs))
+            out = self(zcs, forward=False)
+            dense = lambda t: t.materialize() if isinstance(t, PackedCode) else t                    # noqa: E731
+            return dense(zc), dense(zcs), out, _lib.range_flags(reset=True)
+
+        record = {"tolerance": self.auto_tolerance, "candidates": {}}
+        with torch.cuda.device(device), torch.no_grad():
+            r_zc, r_zcs, r_out, _ = probe("bf16x3")
+            chosen = "bf16x3"
+            for mode in ("f16x2h", "f16x2"):
+                zc, zcs, out, flags = probe(mode)
+                d = (zcs.double() - r_zcs.double()).transpose(0, 1).reshape(zcs.shape[1], -1).norm(dim=1)
+                n = r_zcs.double().transpose(0, 1).reshape(zcs.shape[1], -1).norm(dim=1)
+                errs = {"z_c": rel(zc, r_zc), "z_cs": rel(zcs, r_zcs), "stylized": rel(out, r_out),
+                        "z_cs_worst_channel": float((d / (n + 1e-300)).max()), "range_flags": int(flags)}
+                ok = (flags == 0 and max(errs["z_c"], errs["z_cs"], errs["stylized"]) <= self.auto_tolerance
+                      and errs["z_cs_worst_channel"] <= 10 * self.auto_tolerance)
+                errs["accepted"] = bool(ok)
+                record["candidates"][mode] = errs
+                if ok:
+                    chosen = mode
+                    break
+        self.resolved_precision = record["chosen"] = chosen
+        self.calibration = record
+        return record
 
     # ------------------------------------------------------------------ fp16 range (the narrowed modes only)
     def check_range(self, sample=None):
@@ -243,14 +309,14 @@ class RevResNet(nn.Module):
             with torch.cuda.device(x.device):
                 _lib.check(L.vst_revnet_encode(C.byref(net), C.c_void_p(x.data_ptr()), C.c_void_p(code.data_ptr()),
                                                C.c_void_p(ws.data_ptr()), B, self.in_channel, H, W,
-                                               _PRECISIONS[self.precision], _stream_ptr()), "vst_revnet_encode")
+                                               self._prec(), _stream_ptr()), "vst_revnet_encode")
             return PackedCode(code, H, W, None, None, s)
         z = torch.empty((B, 32, H, W) if s == 2 else (B, 128, H // 2, W // 2), dtype=torch.float32, device=x.device)
         ws = self._get_workspace(L.vst_pass_workspace_bytes(B, H, W), x.device)
         with torch.cuda.device(x.device):
             _lib.check(L.vst_revnet_forward(C.byref(net), C.c_void_p(x.data_ptr()), C.c_void_p(z.data_ptr()),
                                             C.c_void_p(ws.data_ptr()), B, self.in_channel, H, W, s,
-                                            _PRECISIONS[self.precision], _stream_ptr()), "vst_revnet_forward")
+                                            self._prec(), _stream_ptr()), "vst_revnet_forward")
         return z
 
     def _inverse(self, z):
@@ -270,7 +336,7 @@ class RevResNet(nn.Module):
         with torch.cuda.device(z.device):
             _lib.check(L.vst_revnet_inverse(C.byref(net), C.c_void_p(z.data_ptr()), C.c_void_p(x.data_ptr()),
                                             C.c_void_p(ws.data_ptr()), B, self.in_channel, H, W, s,
-                                            _PRECISIONS[self.precision], _stream_ptr()), "vst_revnet_inverse")
+                                            self._prec(), _stream_ptr()), "vst_revnet_inverse")
         return x
 
     def _use_packed(self, B, H, W):
@@ -299,7 +365,7 @@ class RevResNet(nn.Module):
         with torch.cuda.device(code.device):
             if lab is not None:                  # a masked cWCT is pending: one decode per image, a map per row
                 per_image, ms = lab
-                prec = _PRECISIONS[self.precision]
+                prec = self._prec()
                 for b in range(B):
                     a_b, rows_b, plan_b = per_image[b]
                     args = (C.byref(net), C.c_void_p(code[b].data_ptr()), C.c_void_p(a_b.data_ptr()), C.c_void_p(rows_b.data_ptr()),
@@ -313,11 +379,11 @@ class RevResNet(nn.Module):
             if u8:
                 _lib.check(L.vst_revnet_decode_u8(C.byref(net), C.c_void_p(code.data_ptr()), aptr, C.c_void_p(out.data_ptr()),
                                                   C.c_void_p(ws.data_ptr()), B, H, W, self.sp_steps,
-                                                  _PRECISIONS[self.precision], _stream_ptr()), "vst_revnet_decode_u8")
+                                                  self._prec(), _stream_ptr()), "vst_revnet_decode_u8")
             else:
                 _lib.check(L.vst_revnet_decode(C.byref(net), C.c_void_p(code.data_ptr()), aptr, C.c_void_p(out.data_ptr()),
                                                C.c_void_p(ws.data_ptr()), B, self.in_channel, H, W, self.sp_steps,
-                                               _PRECISIONS[self.precision], _stream_ptr()), "vst_revnet_decode")
+                                               self._prec(), _stream_ptr()), "vst_revnet_decode")
         return out
 
     # ------------------------------------------------------------------ uint8 frame edge
@@ -340,14 +406,14 @@ class RevResNet(nn.Module):
             ws = self._get_workspace(L.vst_pass_workspace_bytes(1, H, W), frames.device)
             with torch.cuda.device(frames.device):
                 _lib.check(L.vst_revnet_encode_u8(C.byref(net), C.c_void_p(frames.data_ptr()), C.c_void_p(code.data_ptr()),
-                                                  C.c_void_p(ws.data_ptr()), B, H, W, _PRECISIONS[self.precision],
+                                                  C.c_void_p(ws.data_ptr()), B, H, W, self._prec(),
                                                   _stream_ptr()), "vst_revnet_encode_u8")
             return PackedCode(code, H, W, None, None, s)
         z = torch.empty((B, 32, H, W) if s == 2 else (B, 128, H // 2, W // 2), dtype=torch.float32, device=frames.device)
         ws = self._get_workspace(L.vst_pass_workspace_bytes(B, H, W), frames.device)
         with torch.cuda.device(frames.device):
             _lib.check(L.vst_revnet_forward_u8(C.byref(net), C.c_void_p(frames.data_ptr()), C.c_void_p(z.data_ptr()),
-                                               C.c_void_p(ws.data_ptr()), B, H, W, s, _PRECISIONS[self.precision],
+                                               C.c_void_p(ws.data_ptr()), B, H, W, s, self._prec(),
                                                _stream_ptr()), "vst_revnet_forward_u8")
         return z
 
@@ -366,7 +432,7 @@ class RevResNet(nn.Module):
         ws = self._get_workspace(L.vst_pass_workspace_bytes(B, H, W), z.device)
         with torch.cuda.device(z.device):
             _lib.check(L.vst_revnet_inverse_u8(C.byref(net), C.c_void_p(z.data_ptr()), C.c_void_p(out.data_ptr()),
-                                               C.c_void_p(ws.data_ptr()), B, H, W, s, _PRECISIONS[self.precision],
+                                               C.c_void_p(ws.data_ptr()), B, H, W, s, self._prec(),
                                                _stream_ptr()), "vst_revnet_inverse_u8")
         return out
 
