@@ -13,6 +13,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 LIB_PATH = os.environ.get("VSTNET_HIP_LIB") or os.path.join(PKG_DIR, "libvstnet_hip.so")   # override: A/B builds
+RESOURCES_PATH = os.path.join(PKG_DIR, "libvstnet_hip.resources.txt")    # per-kernel VGPRs / LDS / scratch of the last build
 SOURCES = sorted(glob.glob(os.path.join(PKG_DIR, "csrc", "*.hip")))
 HEADERS = sorted(glob.glob(os.path.join(PKG_DIR, "csrc", "*.h"))) + [os.path.join(REPO_DIR, "include", "vstnet.h")]
 
@@ -81,9 +82,30 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # host code with hidden default visibility: the shared library exports exactly what include/vstnet.h declares
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-Xarch_host", "-fvisibility=hidden",
            "-I", os.path.join(REPO_DIR, "include"), "-o", LIB_PATH] + SOURCES
+    cmd[1:1] = ["-Rpass-analysis=kernel-resource-usage", "-fno-caret-diagnostics"]   # per-kernel registers / LDS / scratch as remarks
     if verbose:
         print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    p = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    remarks = [ln.split("remark:", 1)[1].split("[-Rpass")[0].strip() for ln in p.stderr.splitlines() if "remark:" in ln]
+    other = "\n".join(ln for ln in p.stderr.splitlines() if "remark:" not in ln and "kernel-resource-usage" not in ln)
+    if p.returncode != 0:
+        raise subprocess.CalledProcessError(p.returncode, cmd, stderr=other)
+    if other.strip():
+        print(other)
+    # no kernel of this library may spill: a private segment means scratch traffic in a hot loop (DESIGN.md section 6 has the
+    # story of a 20 % regression from one).  The table is kept next to the library for inspection.
+    table, name = [], None
+    for r in remarks:
+        if r.startswith("Function Name:"):
+            name = r.split(":", 1)[1].strip()
+        elif name and (r.startswith("VGPRs:") or r.startswith("ScratchSize") or r.startswith("LDS Size") or r.startswith("Occupancy")):
+            table.append(f"{name}\t{r}")
+    with open(RESOURCES_PATH, "w") as f:
+        f.write("\n".join(table) + "\n")
+    spills = [t for t in table if "ScratchSize" in t and not t.rstrip().endswith(": 0")]
+    if spills:
+        os.remove(LIB_PATH)
+        raise RuntimeError("kernels with a private segment (register spills):\n" + "\n".join(spills))
     return LIB_PATH
 
 

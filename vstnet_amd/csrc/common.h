@@ -59,7 +59,9 @@ __device__ __forceinline__ int reflect_clamp(int v, int n) {
 // device code), OR-ed together by vst_range_flags (conv.hip).  Read by calibration (RevResNet.check_range), bench.py and tests.
 static __device__ unsigned vst_tu_range_flags;
 __device__ __forceinline__ void vst_note_range(float amax) {
+#ifndef VST_NO_RANGE_CHECK           // (timing-only A/B builds of tools/ab_build.py; the shipped library always checks)
     if (amax > 65504.f) atomicOr(&vst_tu_range_flags, VST_RANGE_SATURATED);
+#endif
 }
 #define VST_DEFINE_TU_RANGE(name)                                                                                    \
     __attribute__((visibility("hidden"))) int name(unsigned* acc, int reset) {                                       \
@@ -75,10 +77,14 @@ __device__ __forceinline__ void vst_note_range(float amax) {
         return VST_OK;                                                                                               \
     }
 
-__device__ __forceinline__ void split8_sp(const float (&f)[8], u32x4& hi, u32x4& lo) {
+// `amax`: the caller's running max |x| over everything it rounds to fp16 (v_max3 only: no compare, no branch in the hot loops);
+// the caller hands it to vst_note_range ONCE, at its end.  The overload without it checks on the spot.
+__device__ __forceinline__ void split8_sp(const float (&f)[8], u32x4& hi, u32x4& lo, float& amax) {
     f16x8 h, l;
-    vst_note_range(fmaxf(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))),
-                         fmaxf(fmaxf(fabsf(f[4]), fabsf(f[5])), fmaxf(fabsf(f[6]), fabsf(f[7])))));
+#ifndef VST_NO_RANGE_CHECK
+    amax = fmaxf(fmaxf(fmaxf(amax, fabsf(f[0])), fmaxf(fabsf(f[1]), fabsf(f[2]))),
+                 fmaxf(fmaxf(fabsf(f[3]), fabsf(f[4])), fmaxf(fmaxf(fabsf(f[5]), fabsf(f[6])), fabsf(f[7]))));
+#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         h[i] = (_Float16)__builtin_amdgcn_fmed3f(f[i], -65504.f, 65504.f);
@@ -86,6 +92,11 @@ __device__ __forceinline__ void split8_sp(const float (&f)[8], u32x4& hi, u32x4&
     }
     hi = __builtin_bit_cast(u32x4, h);
     lo = __builtin_bit_cast(u32x4, l);
+}
+__device__ __forceinline__ void split8_sp(const float (&f)[8], u32x4& hi, u32x4& lo) {
+    float amax = 0.f;
+    split8_sp(f, hi, lo, amax);
+    vst_note_range(amax);
 }
 
 // byte offset of (8-channel group, plane, y, x) in an SP tensor of an HxW image (32 bits: one image's planes are at most

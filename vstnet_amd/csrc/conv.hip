@@ -105,19 +105,21 @@ struct ConvCfg {
 
 // TERMS == 3: bf16 hi / lo (3-term product with split weights); TERMS == 2: fp16 hi / lo (2-term product w_hi (x_hi + x_lo),
 // the arithmetic of conv3.hip; values saturate at +-65504 in the hi part)
-__device__ __forceinline__ void split8_f16(const float4 v0, const float4 v1, uint4& hi, uint4& lo) {
+__device__ __forceinline__ void split8_f16(const float4 v0, const float4 v1, uint4& hi, uint4& lo, float& amax) {
     const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
     u32x4 h, l;
-    split8_sp(f, h, l);
+    split8_sp(f, h, l, amax);
     hi = __builtin_bit_cast(uint4, h);
     lo = __builtin_bit_cast(uint4, l);
 }
 
-__device__ __forceinline__ void split4_f16(const float4 v, uint2& hi, uint2& lo) {
+__device__ __forceinline__ void split4_f16(const float4 v, uint2& hi, uint2& lo, float& amax) {
     const float f[4] = {v.x, v.y, v.z, v.w};
     typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
     f16x4 h, l;
-    vst_note_range(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))));
+#ifndef VST_NO_RANGE_CHECK
+    amax = fmaxf(fmaxf(amax, fabsf(f[0])), fmaxf(fmaxf(fabsf(f[1]), fabsf(f[2])), fabsf(f[3])));
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float c = __builtin_amdgcn_fmed3f(f[i], -65504.f, 65504.f);
@@ -220,8 +222,9 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, float* out_img, in
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh), __builtin_bit_cast(f16x8, xl), acc, 0, 0, 0); \
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh), __builtin_bit_cast(f16x8, xh), acc, 0, 0, 0); \
     }
-#define SPLIT8_T(v0_, v1_, h_, l_) { if constexpr (TERMS == 3) split8(v0_, v1_, h_, l_); else split8_f16(v0_, v1_, h_, l_); }
-#define SPLIT4_T(v_, h_, l_) { if constexpr (TERMS == 3) split4(v_, h_, l_); else split4_f16(v_, h_, l_); }
+// (range_amax: the kernel's running max |x| of what it rounds to fp16, handed to vst_note_range once at its end)
+#define SPLIT8_T(v0_, v1_, h_, l_) { if constexpr (TERMS == 3) split8(v0_, v1_, h_, l_); else split8_f16(v0_, v1_, h_, l_, range_amax); }
+#define SPLIT4_T(v_, h_, l_) { if constexpr (TERMS == 3) split4(v_, h_, l_); else split4_f16(v_, h_, l_, range_amax); }
 
 #ifndef VST_EARLY_OLD
 #define VST_EARLY_OLD 1
@@ -242,6 +245,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const int lrow = lane & 15, kg = lane >> 4;
     int bx, by, bz;
     if (!xcd_tile(a, bx, by, bz)) return;
+    float range_amax = 0.f;
     VST_TRACE_BEGIN(2)
     const int tx0 = bx * C::TW, ty0 = by * C::TH;
     const int b = bz / C::NCOT, co0 = (bz % C::NCOT) * C::NT;
@@ -410,11 +414,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                     f8[e] = v > 0.f ? v : 0.f;
                 }
                 u32x4 hi, lo;
-                split8_sp(f8, hi, lo);
+                split8_sp(f8, hi, lo, range_amax);
                 *(u32x4*)(sp_img + sp_offset(j * 4 + kg, 0, oy, ox, a.Hout, a.Wout)) = hi;
                 *(u32x4*)(sp_img + sp_offset(j * 4 + kg, 1, oy, ox, a.Hout, a.Wout)) = lo;
             }
         }
+        vst_note_range(range_amax);
         return;
     }
     if constexpr (OUT_H16) {
@@ -429,14 +434,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                 const float r[4] = {acc[m][n][0] + bias[n].x, acc[m][n][1] + bias[n].y, acc[m][n][2] + bias[n].z, acc[m][n][3] + bias[n].w};
                 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
                 f16x4 h;
-                vst_note_range(fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3])));
+                range_amax = fmaxf(fmaxf(range_amax, r[0]), fmaxf(fmaxf(r[1], r[2]), r[3]));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) h[e] = (_Float16)__builtin_amdgcn_fmed3f(r[e], 0.f, 65504.f);     // ReLU, saturating
                 *(f16x4*)(o16 + ((size_t)oy * a.Wout + ox) * COUT + co) = h;
             }
+        vst_note_range(range_amax);
         VST_TRACE_END(2)
         return;
     }
+    if constexpr (TERMS == 2) vst_note_range(range_amax);
     if (OUT_STATE && !EARLY_OLD) fetch_old();
     if (interior) store_tile<COUT, OUT_STATE, C::MR, C::NB, true>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, acc, bias, old);
     else store_tile<COUT, OUT_STATE, C::MR, C::NB>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, acc, bias, old);
@@ -513,6 +520,7 @@ __global__ __launch_bounds__(256, (MID == 16 && TERMS == 2) ? 3 : 1) void conv_p
     const int lrow = lane & 15, kg = lane >> 4;
     int bx, by, b;
     if (!xcd_tile(a, bx, by, b)) return;
+    float range_amax = 0.f;
     VST_TRACE_BEGIN(1)
     const int tx0 = bx * C::TW, ty0 = by * C::TH;
     const int H = a.Hout, W = a.Wout;                        // h1, h2 and the output view share one resolution
@@ -737,6 +745,7 @@ __global__ __launch_bounds__(256, (MID == 16 && TERMS == 2) ? 3 : 1) void conv_p
         }
     }
     load_bias<CH, C::NB>(a, 4 * kg, bias);
+    if constexpr (TERMS == 2) vst_note_range(range_amax);
     if (!EARLY_OLD) { PAIR_FETCH_OLD(); }
 #undef PAIR_FETCH_OLD
     if (interior) store_tile<CH, true, C::MR, C::NB, true>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, 4 * kg, acc, bias, old);

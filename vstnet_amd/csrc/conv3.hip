@@ -202,7 +202,8 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
                                       res[m_][2 * j_ + 1][0], res[m_][2 * j_ + 1][1], res[m_][2 * j_ + 1][2],                 \
                                       res[m_][2 * j_ + 1][3]};                                                                \
                 u32x4 hi_, lo_;                                                                                               \
-                split8_sp(f8_, hi_, lo_);                                                                                     \
+                float unused_;                              /* (range check: at `finish`, once per slice) */                  \
+                split8_sp(f8_, hi_, lo_, unused_);                                                                            \
                 const int cig_ = pend_cot * 8 + j_ * 4 + kg;                                                                  \
                 if (OUT1) {                                                                                                   \
                     *(u32x4*)(sp_img + sp_offset1(cig_, oy_, ox, H, W)) = hi_;                                                \
@@ -329,6 +330,16 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
                     }
                     acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
+            if (sp_img) {                                    // these values are about to be rounded to fp16: range flag, once per slice
+                float amax = 0.f;
+#pragma unroll
+                for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        amax = fmaxf(fmaxf(fmaxf(amax, fabsf(res[m][n][0])), fabsf(res[m][n][1])),
+                                     fmaxf(fabsf(res[m][n][2]), fabsf(res[m][n][3])));
+                vst_note_range(amax);
+            }
             pending = true;
             pend_cot = cot;
             pend_slot0 = 0;
