@@ -187,6 +187,11 @@ def main():
             with torch.cuda.stream(st):
                 return stylize_batch(**kw)
 
+        # setup, not warm-up: one untimed step per stream, so that every stream's pass workspace (288 B per pixel: 4.8 GB at
+        # 4096 x 4096) exists before the W warm-up steps — with W < streams an allocation would otherwise land in the timed region
+        for _ in streams:
+            step()
+        torch.cuda.synchronize()
         elapsed, per_rank_s = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, world,
                                           device=dev if use_nccl else "cpu", return_all=True)
         assert torch.isfinite(step()).all()

@@ -579,6 +579,58 @@ def test_cwct_use_double_golden(golden):
     assert_close(cwd.whitening(x2.cuda()), cpu_ref.whitening(x2.double()).float(), 5e-6, "use_double whitening (cond 1e6)")
 
 
+def test_cwct_every_route_vs_oracle():
+    """each entry of cWCT.ROUTES, taken on purpose, against the oracle — `last_route` says which one ran"""
+    from models.cWCT import cWCT
+    from vstnet_amd.code import PackedCode
+    rng = np.random.default_rng(5)
+    took = set()
+
+    def codes(N, h, w, hs, ws):
+        return (T(rng.standard_normal((1, N, h, w)).astype(np.float32)) * 0.7 + 0.2,
+                T(rng.standard_normal((1, N, hs, ws)).astype(np.float32)) * 1.2 - 0.1)
+    # dense, every N
+    for N in (16, 32, 64, 128):
+        c, s = codes(N, 24, 40, 20, 36)
+        cw = cWCT()
+        assert_close(cw.transfer(c.cuda(), s.cuda()), cpu_ref.transfer(c, s), 2e-4, f"dense N={N}", tol_max=TOL)
+        assert cw.last_route == "dense"
+        took.add(cw.last_route)
+    # masked: single pass (N = 32, 128), per label (N = 16)
+    cm, sm = synthetic_mask(24, 40, 3, seed=1)[None], synthetic_mask(20, 36, 3, seed=2, speck=False)[None]
+    for N, want in ((32, "masked_single_pass"), (16, "masked_per_label")):
+        c, s = codes(N, 24, 40, 20, 36)
+        cw = cWCT()
+        assert_close(cw.transfer(c.cuda(), s.cuda(), cm, sm), cpu_ref.transfer_seg(c, s, cm, sm), 5e-4, want, tol_max=5e-3)
+        assert cw.last_route == want
+        took.add(want)
+    # fp64, unmasked and masked
+    c, s = codes(32, 24, 40, 20, 36)
+    cwd = cWCT(use_double=True)
+    assert_close(cwd.transfer(c.cuda(), s.cuda()), cpu_ref.transfer(c, s, use_double=True), 2e-6, "dense_f64")
+    took.add(cwd.last_route)
+    assert_close(cwd.transfer(c.cuda(), s.cuda(), cm, sm), cpu_ref.transfer_seg(c, s, cm, sm, use_double=True), 2e-6, "masked f64")
+    took.add(cwd.last_route)
+    # packed rows, unmasked and masked (photorealistic code from the network)
+    net, sd, sp = make_net("photo")
+    xc, xs = synthetic_frames(1, 24, 40, seed=1), synthetic_frames(1, 24, 40, seed=2)
+    cw = cWCT()
+    with torch.no_grad():
+        z, zs = net(xc.cuda()), net(xs.cuda())
+        t = cw.transfer(z, zs)
+        assert isinstance(t, PackedCode) and cw.last_route == "packed_rows"
+        took.add(cw.last_route)
+        assert_close(t.materialize(), cpu_ref.transfer(z.materialize().cpu(), zs.materialize().cpu()), 2e-5, "packed_rows")
+        cm2, sm2 = synthetic_mask(24, 40, 3, seed=3)[None], synthetic_mask(24, 40, 3, seed=4, speck=False)[None]
+        plan = cw.learn_slots(cw.plan_masks(cm2, sm2, z.shape, zs.shape, z.device))
+        tm = cw.transfer_with_plan(z, zs, plan)
+        assert isinstance(tm, PackedCode) and cw.last_route == "masked_packed_rows"
+        took.add(cw.last_route)
+        assert_close(tm.materialize(), cpu_ref.transfer_seg(z.materialize().cpu(), zs.materialize().cpu(), cm2, sm2), 2e-4,
+                     "masked_packed_rows", tol_max=TOL)
+    assert took == set(cWCT.ROUTES), set(cWCT.ROUTES) - took
+
+
 def test_native_runner_matches_python_path(tmp_path):
     """tools/vst_run (C++ host, C ABI only — no Python / torch in the process) == the drop-in classes, bit for bit"""
     import subprocess

@@ -160,6 +160,32 @@ def test_packed_code_notices_writes():
         assert not P(rows, 4, 4).with_affines(torch.zeros(2, 1056)).stale
 
 
+def test_cwct_route_table_is_total_and_consistent():
+    """the cWCT routes (layout x mask x N x slots x use_double) are chosen in ONE function; enumerate it.
+    Every combination maps to a documented route, and the structural rules hold (the GPU side — each route against the
+    oracle, with `last_route` asserted — is tests/test_gpu_parity.py::test_cwct_every_route_vs_oracle)."""
+    import itertools
+    from models.cWCT import cWCT
+    seen = set()
+    for packed, masked, N, sp, slots, dbl in itertools.product((False, True), (False, True), (16, 32, 64, 128), (1, 2),
+                                                               (0, 1, 8, 9, 32), (False, True)):
+        r = cWCT.route(packed, masked, N, sp, slots, dbl)
+        assert r in cWCT.ROUTES
+        seen.add(r)
+        if dbl:
+            assert r.endswith("_f64")                                  # fp64 never touches the packed rows
+        if "packed" in r:
+            assert packed and not dbl and ((N, sp) in ((32, 2), (128, 1)))
+        if r == "masked_packed_rows":
+            assert masked and N == 32 and sp == 2 and 1 <= slots <= 8
+        if masked and not dbl and N == 16:
+            assert r == "masked_per_label"
+        assert masked == r.startswith("masked")
+    assert seen == set(cWCT.ROUTES)                                    # no dead entry in the table
+    with pytest.raises(NotImplementedError):
+        cWCT.route(False, False, 48)
+
+
 def test_product_does_not_import_oracle():
     for root, _, files in os.walk(os.path.join(REPO, "vstnet_amd")):
         for f in files:

@@ -1080,6 +1080,9 @@ static int launch_conv_s2_planes(const ConvArgs& a, int B, hipStream_t st) {
 #ifndef VST_PAIR
 #define VST_PAIR 1
 #endif
+#ifndef VST_PAIR_MR2_T3
+#define VST_PAIR_MR2_T3 0
+#endif
 #ifndef VST_PAIR_MR2
 #define VST_PAIR_MR2 0       // 1: the 64-channel 2-term pair on 8 x 16 tiles (measured, not kept: DESIGN.md)
 #endif
@@ -1103,9 +1106,10 @@ static int launch_pair(const ConvArgs& a, int B, int precision, hipStream_t st) 
     // (-DVST_PAIR_MR2=1: the 64-channel blocks' 2-term pair on 8 x 16 tiles - 33 KB of LDS, 96 VGPRs, four workgroups per CU,
     // eight per CU and launch at 1024 x 1024 in two even rounds instead of 3 + 1: 7 % faster alone, 0.6 % slower in the frame)
     constexpr int MRT = (MID == 16 && VST_PAIR_MR2) ? 2 : 4;
-    auto kern = t2 ? conv_pair_kernel<MID, CH, T2, MRT> : conv_pair_kernel<MID, CH, 3, 4>;
-    const int lds = t2 ? PairCfg<MID, CH, T2, MRT>::LDS_BYTES : PairCfg<MID, CH, 3, 4>::LDS_BYTES;
-    const int th = t2 ? 4 * MRT : 16;
+    constexpr int MRT3 = (MID == 16 && VST_PAIR_MR2_T3) ? 2 : 4;        // the same experiment for the bf16 3-term pair
+    auto kern = t2 ? conv_pair_kernel<MID, CH, T2, MRT> : conv_pair_kernel<MID, CH, 3, MRT3>;
+    const int lds = t2 ? PairCfg<MID, CH, T2, MRT>::LDS_BYTES : PairCfg<MID, CH, 3, MRT3>::LDS_BYTES;
+    const int th = t2 ? 4 * MRT : 4 * MRT3;
     static std::atomic<unsigned> attr_done[2];
     if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, lds, &attr_done[t2 ? 1 : 0])) return rc_;
     ConvArgs t = a;

@@ -66,6 +66,7 @@ class cWCT(nn.Module):
         self.resize_masks = resize_masks
         self._ws = None
         self.last_info = None      # device int32 [2+n_styles]: content retries, overflow flag, style retries
+        self.last_route = None     # key of ROUTES the last transfer took
 
     # ------------------------------------------------------------------ low-level wrappers
     def _workspace(self, nbytes, device):
@@ -117,10 +118,43 @@ class cWCT(nn.Module):
                        "vst_cwct_stats_code")
         return out
 
-    def _is_packed(self, x):
-        if self.use_double:
-            return False
-        return self._is_packed_code(x)
+    # ------------------------------------------------------------------ the ONE place where a transfer's route is chosen
+    # (code layout x mask x N x slot count x use_double) -> which kernels run.  The arithmetic of the dense applies (exact fp32
+    # vs bf16 split operands for N >= 64) is the `precision` argument of vst_cwct_apply_prec / vst_cwct_apply_labels and is
+    # chosen inside the library; everything else is decided here and recorded in `last_route`.
+    ROUTES = {
+        "packed_rows": "unmasked, code in the coupling blocks' layout: vst_cwct_stats_code + factor; the map stays pending and "
+                       "is applied by the inverse pass (vst_revnet_decode)",
+        "dense": "unmasked NCHW code: vst_cwct_stats + factor + vst_cwct_apply_prec",
+        "masked_packed_rows": "masked, photorealistic packed code, 1..8 label slots known: vst_cwct_stats_labels_code + "
+                              "factor_labels; per-row maps pending (vst_revnet_decode_labels)",
+        "masked_single_pass": "masked NCHW code, N in {32, 64, 128}: vst_cwct_stats_labels + factor_labels + apply_labels",
+        "masked_per_label": "masked NCHW code, N = 16: one vst_cwct_stats / factor / apply per valid label",
+        "dense_f64": "use_double, unmasked: vst_cwct_stats_f64 + factor_f64 + apply_f64 on the NCHW code",
+        "masked_per_label_f64": "use_double, masked: the fp64 calls per valid label (the reference's loop, cWCT.py:83-103)",
+    }
+
+    @staticmethod
+    def route(packed, masked, N, sp_steps=2, max_slots=0, use_double=False):
+        """Name of the route (a key of ROUTES) for a code that is / is not a usable PackedCode (`packed`: no pending map, not
+        written to), with / without masks, N channels, `max_slots` label slots known to the host (0 = never read back)."""
+        if N not in _SUPPORTED_N:
+            raise NotImplementedError(f"HIP cWCT supports N in {_SUPPORTED_N}, got {N}")
+        if use_double:
+            return "masked_per_label_f64" if masked else "dense_f64"
+        if not masked:
+            return "packed_rows" if packed and ((N == 32 and sp_steps == 2) or (N == 128 and sp_steps == 1)) else "dense"
+        if N == 16:
+            return "masked_per_label"
+        if packed and N == 32 and sp_steps == 2 and 1 <= int(max_slots) <= 8:
+            return "masked_packed_rows"
+        return "masked_single_pass"
+
+    def _route_of(self, content_feat, masked, max_slots=0):
+        r = self.route(self._is_packed_code(content_feat), masked, content_feat.shape[1],
+                       getattr(content_feat, "sp_steps", 2), max_slots, self.use_double)
+        self.last_route = r
+        return r
 
     @staticmethod
     def _is_packed_code(x):
@@ -189,7 +223,7 @@ class cWCT(nn.Module):
         assert len(styl_feat_list) == len(alpha_s_list)
         B, N, cH, cW = content_feat.shape
         in_dtype = content_feat.dtype
-        packed = self._is_packed(content_feat)     # statistics on the packed rows; the map is applied by the inverse pass
+        packed = self._route_of(content_feat, masked=False) == "packed_rows"   # statistics on the packed rows; map applied by the inverse pass
         c = None if packed else self._prep(content_feat).reshape(B, N, -1)
         styles = []
         for sf in styl_feat_list:
@@ -241,7 +275,7 @@ class cWCT(nn.Module):
         overwrites a contiguous fp32 content code instead of allocating the result (like the reference's masked path,
         cWCT.py:62,103; one 128 MiB buffer less per 1024x1024 frame in flight)."""
         B, N, cH, cW = content_feat.shape
-        if self._is_packed(content_feat):          # packed rows: nothing is written here, the inverse pass applies the map
+        if self._route_of(content_feat, masked=False) == "packed_rows":   # nothing is written here, the inverse pass applies the map
             affines = [self.factor(self.stats_code(content_feat, b), [style_stats[b if len(style_stats) > 1 else 0]], [1.0],
                                    alpha_c, N) for b in range(B)]
             return content_feat.with_affines(torch.stack(affines))
@@ -256,7 +290,7 @@ class cWCT(nn.Module):
 
     def _transfer_seg(self, content_feat, style_feat, cmask, smask):
         """models/cWCT.py:49-109."""
-        if content_feat.shape[1] == 16 or self.use_double:
+        if self._route_of(content_feat, masked=True).startswith("masked_per_label"):
             # no matrix-core form at N = 16, no single-pass fp64 form: one statistics + apply pass per label (cWCT.py:83-103)
             return self._transfer_seg_per_label(content_feat, style_feat, cmask, smask)
         plan = self.plan_masks(cmask, smask, content_feat.shape, style_feat.shape, content_feat.device)
@@ -369,8 +403,10 @@ class cWCT(nn.Module):
         if self.use_double:
             raise NotImplementedError("transfer_with_plan (this repo's cached-mask extension) has no fp64 form: with "
                                       "use_double=True call transfer(content, style, cmask, smask)")
-        if self._is_packed(content_feat) and content_feat.sp_steps == 2 and 1 <= int(plan.max_slots) <= 8:
+        if self._route_of(content_feat, masked=True, max_slots=plan.max_slots) == "masked_packed_rows":
             return self._transfer_with_plan_packed(content_feat, style_feat, plan)
+        if self.last_route != "masked_single_pass":
+            raise NotImplementedError("transfer_with_plan needs N in (32, 64, 128)")
         in_dtype = content_feat.dtype
         c = self._prep(content_feat).reshape(B, N, -1)
         s = None
