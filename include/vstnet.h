@@ -84,6 +84,9 @@ int vst_normalize_block(float* w1, float* b1, float* w4, float* b4, float* w7, i
 /* *flags_host = OR of the flags raised on the current device; reset != 0 clears them.  Synchronises the device (a calibration
  * / diagnostic call: RevResNet.check_range, bench.py, tests), never called by the passes themselves. */
 int vst_range_flags(unsigned* flags_host, int reset);
+/* the same without synchronising: four words (their OR = the flags) copied to DEVICE memory in stream order - a frame loop
+ * appends them to the frame's own D2H copy and looks at them when it retires the frame (vstnet_amd/pipeline.py) */
+int vst_range_flags_async(unsigned* flags4_dev, void* stream);
 
 typedef struct vst_conv_weights {
     const void* packed;   /* from vst_pack_conv */

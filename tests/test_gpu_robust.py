@@ -230,6 +230,32 @@ def test_saturation_is_flagged_not_silent(tmp_path):
     assert rel_l2(z, zr) <= 5e-5
 
 
+def test_frame_pipeline_reports_saturation_per_frame():
+    """the video loop (vstnet_amd/pipeline.py) carries the range flags with every frame: a clip that saturates an fp16 operand
+    fails at the frame that did it (here: a checkpoint with h1 scaled by 2^18 and the pack-time normalisation and the load-time
+    probe both switched off, i.e. exactly the case those two exist to prevent); bf16x3 runs the same clip"""
+    from models.cWCT import cWCT
+    from vstnet_amd.pipeline import FramePipeline
+    sd = rescale_state_dict(synthetic_state_dict(1234, 16, 2), 2.0 ** 18, 1.0)
+    frames = [(synthetic_frames(1, 32, 48, seed=60 + i)[0].permute(1, 2, 0) * 255).byte().numpy() for i in range(4)]
+    for precision in ("f16x2h", "bf16x3"):
+        net, _ = _net(sd, "photo", precision, normalize_intermediates=False, calibrate_on_load=False)
+        cw = cWCT(precision=precision)
+        _lib.range_flags(reset=True)
+        with torch.no_grad():
+            stats = cw.style_stats(net.forward_u8(torch.from_numpy(frames[0])[None].cuda()))
+        _lib.range_flags(reset=True)
+        pipe = FramePipeline(net, lambda z, i: cw.transfer_with_stats(z, stats), 32, 48, depth=2, compute_streams=1)
+        got = []
+        if precision == "bf16x3":
+            assert pipe.run(frames, lambda i, a: got.append(i)) == 4 and got == [0, 1, 2, 3]
+        else:
+            with pytest.raises(RuntimeError, match="range flags"):
+                pipe.run(frames, lambda i, a: got.append(i))
+            assert got == []                                   # the first frame already saturated: nothing was handed on
+    _lib.range_flags(reset=True)
+
+
 def test_load_time_calibration_rejects_an_unrepresentable_checkpoint():
     """a conv weight of 1e6 (fp16: Inf) with the normalisation off: the fp16 modes refuse the checkpoint at the first call
     (RuntimeError naming bf16x3), bf16x3 runs it; with the normalisation on the same checkpoint is fine in every mode."""

@@ -77,7 +77,7 @@ def main():
             print(line, flush=True)
     x = synthetic_frames(1, H, W).to(dev)
     for name in args.modes.split(","):
-        net.precision = name
+        net.precision = net.resolved_precision = name
         z = net(x)
         for _ in range(3):
             net(net(x), forward=False)

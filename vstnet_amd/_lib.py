@@ -36,7 +36,7 @@ EXPORTS = [
     "vst_cwct_stats_code_workspace_bytes", "vst_cwct_stats_code", "vst_cwct_apply_code",
     "vst_mask_to_code", "vst_cwct_stats_labels_code_workspace_bytes", "vst_cwct_stats_labels_code", "vst_cwct_apply_labels_code",
     "vst_revnet_decode_labels", "vst_revnet_decode_labels_u8", "vst_pass_sub_batch",
-    "vst_normalize_block", "vst_range_flags",
+    "vst_normalize_block", "vst_range_flags", "vst_range_flags_async",
     "vst_cwct_stats_f64_workspace_bytes", "vst_cwct_stats_f64", "vst_cwct_factor_f64_workspace_bytes", "vst_cwct_factor_f64",
     "vst_cwct_apply_f64",
 ]
@@ -145,6 +145,7 @@ def lib() -> C.CDLL:
         "vst_pack_conv": (i, [vp, i, i, vp, vp]),
         "vst_normalize_block": (i, [vp, vp, vp, vp, vp, i, i, i, vp, vp]),
         "vst_range_flags": (i, [C.POINTER(C.c_uint), i]),
+        "vst_range_flags_async": (i, [vp, vp]),
         "vst_pack_input": (i, [vp, vp, vp, i, i, i, i, vp]),
         "vst_unpack_output": (i, [vp, vp, i, i, i, i, vp]),
         "vst_pack_input_u8": (i, [vp, vp, vp, i, i, i, vp]),

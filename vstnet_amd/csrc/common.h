@@ -75,6 +75,10 @@ __device__ __forceinline__ void vst_note_range(float amax) {
             if (e != hipSuccess) return (int)e;                                                                      \
         }                                                                                                            \
         return VST_OK;                                                                                               \
+    }                                                                                                                \
+    __attribute__((visibility("hidden"))) int name##_async(unsigned* dst_dev, hipStream_t st) {                      \
+        return (int)hipMemcpyFromSymbolAsync(dst_dev, HIP_SYMBOL(vst_tu_range_flags), sizeof(unsigned), 0,           \
+                                             hipMemcpyDeviceToDevice, st);                                           \
     }
 
 // `amax`: the caller's running max |x| over everything it rounds to fp16 (v_max3 only: no compare, no branch in the hot loops);
@@ -194,6 +198,10 @@ int vst_range_tu_conv(unsigned* acc, int reset);
 int vst_range_tu_conv3(unsigned* acc, int reset);
 int vst_range_tu_layout(unsigned* acc, int reset);
 int vst_range_tu_cwct(unsigned* acc, int reset);
+int vst_range_tu_conv_async(unsigned* dst_dev, hipStream_t st);
+int vst_range_tu_conv3_async(unsigned* dst_dev, hipStream_t st);
+int vst_range_tu_layout_async(unsigned* dst_dev, hipStream_t st);
+int vst_range_tu_cwct_async(unsigned* dst_dev, hipStream_t st);
 extern "C" VST_INTERNAL int vst_pack_input_k(const float* x, const uint8_t* x_u8, float* s1, float* s2, int B, int C, int H, int W,
                                 const float* addk, void* stream);
 extern "C" VST_INTERNAL int vst_block0_const(const vst_block_weights* w0, float* k16, void* stream);

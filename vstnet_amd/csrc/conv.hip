@@ -1203,6 +1203,15 @@ int vst_range_flags(unsigned* flags_host, int reset) {
     return VST_OK;
 }
 
+int vst_range_flags_async(unsigned* flags4_dev, void* stream) {
+    if (!flags4_dev) return VST_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = vst_range_tu_conv_async(flags4_dev + 0, st)) return rc;
+    if (int rc = vst_range_tu_conv3_async(flags4_dev + 1, st)) return rc;
+    if (int rc = vst_range_tu_layout_async(flags4_dev + 2, st)) return rc;
+    return vst_range_tu_cwct_async(flags4_dev + 3, st);
+}
+
 int vst_profile_begin(int kernel_id, int max_records) {
     if ((kernel_id <= 0 && kernel_id != VST_KERNEL_ALL) || max_records <= 0) return VST_E_ARG;
     if (max_records > VST_PROFILE_MAX_RECORDS) max_records = VST_PROFILE_MAX_RECORDS;

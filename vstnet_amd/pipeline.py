@@ -45,6 +45,12 @@ class FramePipeline:
             self.h_in_np, self.h_out_np = self.h_in.numpy(), self.h_out.numpy()
             self.d_in = torch.empty((depth, 1, height, width, 3), dtype=torch.uint8, device=self.device)
             self.s_comp = [torch.cuda.Stream(device=self.device) for _ in range(max(1, compute_streams))]
+            # fp16 modes: the library's range flags travel with every frame (4 words, appended to its D2H copy) and are looked
+            # at when the frame is retired - saturation is an error of THAT frame, not a silent clamp somewhere in the clip
+            self.d_flags = torch.zeros((depth, 4), dtype=torch.int32, device=self.device)
+            self.h_flags = torch.zeros((depth, 4), dtype=torch.int32).pin_memory()
+            self.h_flags_np = self.h_flags.numpy()
+            self.flag_check = [False] * depth
             self.done = [torch.cuda.Event() for _ in range(depth)]
             self.consumed = [torch.cuda.Event() for _ in range(depth)]      # compute(i) has read d_in[slot]
 
@@ -69,11 +75,22 @@ class FramePipeline:
             if tuple(out.shape) != (1, self.Ho, self.Wo, 3) or out.dtype != torch.uint8:
                 raise RuntimeError(f"decode returned {out.dtype} {tuple(out.shape)}, expected uint8 (1,{self.Ho},{self.Wo},3)")
             self.h_out[k].copy_(out[0], non_blocking=True)
+            self.flag_check[k] = getattr(self.net, "resolved_precision", None) in ("f16x2", "f16x2h")
+            if self.flag_check[k]:
+                from . import _lib
+                import ctypes as C
+                _lib.check(_lib.lib().vst_range_flags_async(C.c_void_p(self.d_flags[k].data_ptr()), C.c_void_p(sc.cuda_stream)),
+                           "vst_range_flags_async")
+                self.h_flags[k].copy_(self.d_flags[k], non_blocking=True)
             self.done[k].record(sc)
 
     def _retire(self, i, sink):
         k = i % self.depth
         self.done[k].synchronize()
+        if self.flag_check[k] and self.h_flags_np[k].any():
+            flags = int(np.bitwise_or.reduce(self.h_flags_np[k]))
+            raise RuntimeError(f"frame {i}: fp16 range flags 0x{flags:x} raised by precision='{self.net.resolved_precision}' "
+                               "(1 = an activation saturated at +-65504): this checkpoint / input needs precision='bf16x3'")
         sink(i, self.h_out_np[k])        # a view of the pinned slot: valid until `depth` more frames are submitted
 
     def run(self, frames, sink, start_index=0):
