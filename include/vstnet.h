@@ -264,6 +264,24 @@ int vst_cwct_apply_labels(const float* x, float* y, int N, long L, const float* 
  * vst_cwct_factor.  `out` may alias `stats`; info = int[1] retry count. */
 int vst_cwct_prefactor(const double* stats, int N, float eps, double* out, int* info, void* stream);
 
+/* ---- generic-architecture RevResNet ops -------------------------------------------------------------------------------------
+ * models/RevResNet.py:166-201 accepts any nBlocks / nStrides / nChannels / mult / kernel / in_channel / hidden_dim / sp_steps; the
+ * whole-pass entry points above implement the published architecture ([10,10,10] / [1,2,2] / [16,64,256], mult 4, kernel 3).
+ * Any other architecture runs on these: plain NCHW fp32 tensors, exact fp32 FMA (the slow, complete path; csrc/generic.hip).
+ *   vst_generic_conv : ReflectionPad2d((K-1)/2) + Conv2d(K, stride, bias=True) of residual_block.conv (:79-88), K odd <= 7,
+ *                      stride 1 or 2; relu != 0 applies ReLU; old != NULL: out = old + sign * conv (the coupling of
+ *                      residual_block.forward / .inverse, :96-116; out may alias old).  w = OIHW, out = [B,Cout,Ho,Wo],
+ *                      Ho = (H + 2 pad - K) / stride + 1.
+ *   vst_generic_squeeze / _unsqueeze : :34-43 (D, H, W = channels and size of the UNsqueezed tensor, H, W even).
+ *   vst_generic_copy_channels : dst[b, d0 + k] = src[b, c0 + k], k < n  (split / merge / injective_pad, :8-31); vst_generic_zero. */
+int vst_generic_conv(const float* x, const float* w, const float* bias, const float* old, float sign, int relu, float* out, int B,
+                     int Cin, int Cout, int H, int W, int K, int stride, void* stream);
+int vst_generic_squeeze(const float* x, float* y, int B, int D, int H, int W, void* stream);
+int vst_generic_unsqueeze(const float* y, float* x, int B, int D, int H, int W, void* stream);
+int vst_generic_copy_channels(const float* src, float* dst, int B, int C_src, int c0, int n, long HW, int C_dst, int d0,
+                              void* stream);
+int vst_generic_zero(float* dst, size_t n_floats, void* stream);
+
 /* ---- fp64 cWCT: cWCT(use_double=True), models/cWCT.py:13-16,35-47,66,106,220,238,259 -------------------------------------
  * The reference converts the features to double and runs mean / covariance / Cholesky (with the same jitter schedule) / inverse
  * / both products in fp64, then converts back.  Same records as the fp32 calls (stats = double[1 + N + N*N], info as in

@@ -76,8 +76,9 @@ def unsqueeze(x):
 
 # --------------------------------------------------------------------------- R-4 / R-5 block
 def _conv(x, w, b, stride=1):
-    # ReflectionPad2d(1) + Conv2d(k=3, padding=0, bias=True): models/RevResNet.py:79-88
-    return F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w, b, stride=stride)
+    # ReflectionPad2d((k-1)//2) + Conv2d(k, padding=0, bias=True): models/RevResNet.py:73,79-88 (k = 3 in the published nets)
+    p = (w.shape[-1] - 1) // 2
+    return F.conv2d(F.pad(x, (p, p, p, p), mode="reflect") if p else x, w, b, stride=stride)
 
 
 def residual_F(x2, sd, prefix, stride):
@@ -106,13 +107,29 @@ def block_inverse(x2, y1, sd, prefix, stride):
 
 
 # --------------------------------------------------------------------------- R-6 / R-7 network
-def revnet_forward(x, sd, sp_steps=2):
-    """models/RevResNet.py:210-223 + channel_reduction.forward :131-146."""
-    x = inj_pad_fwd(x, 32 - x.shape[1])
+def arch_stack(arch):
+    """[(stride, channel)] of the stack for a constructor-argument set (block_stack, models/RevResNet.py:190-201);
+    arch = dict(nBlocks, nStrides, nChannels, ...), None = the published architecture."""
+    if arch is None:
+        return STACK
+    out = []
+    for ch, depth, st in zip(arch["nChannels"], arch["nBlocks"], arch["nStrides"]):
+        out += [(st, ch)] + [(1, ch)] * (depth - 1)
+    return out
+
+
+def revnet_forward(x, sd, sp_steps=2, arch=None):
+    """models/RevResNet.py:210-223 + channel_reduction.forward :131-146.  arch (optional): the reference's other constructor
+    arguments — dict(nBlocks, nStrides, nChannels, hidden_dim[, in_channel]); mult and kernel are implied by the weight shapes."""
+    stack = arch_stack(arch)
+    c0 = stack[0][1]
+    x = inj_pad_fwd(x, 2 * c0 - x.shape[1])
     x1, x2 = split(x)
-    for i, (stride, _) in enumerate(STACK):
+    for i, (stride, _) in enumerate(stack):
         x1, x2 = block_forward(x1, x2, sd, f"stack.{i}.", stride)
-    x1, x2 = split(merge(x1, x2))               # channel_reduction.forward: split, inj_pad(0)
+    x1, x2 = split(merge(x1, x2))               # channel_reduction.forward: split, inj_pad (0 in the published nets)
+    cr_pad = 0 if arch is None else arch["hidden_dim"] * 4 ** sp_steps - stack[-1][1]
+    x1, x2 = inj_pad_fwd(x1, cr_pad), inj_pad_fwd(x2, cr_pad)
     for i in range(2):
         x1, x2 = block_forward(x1, x2, sd, f"channel_reduction.block_list.{i}.", 1)
     z = merge(x1, x2)
@@ -121,17 +138,20 @@ def revnet_forward(x, sd, sp_steps=2):
     return z
 
 
-def revnet_inverse(z, sd, sp_steps=2, in_channel=3):
+def revnet_inverse(z, sd, sp_steps=2, in_channel=3, arch=None):
     """models/RevResNet.py:225-239 + channel_reduction.inverse :148-163."""
+    stack = arch_stack(arch)
     for _ in range(sp_steps):
         z = squeeze(z)
     a, b = split(z)
     for i in (1, 0):
         a, b = block_inverse(a, b, sd, f"channel_reduction.block_list.{i}.", 1)
+    cr_pad = 0 if arch is None else arch["hidden_dim"] * 4 ** sp_steps - stack[-1][1]
+    a, b = inj_pad_inv(a, cr_pad), inj_pad_inv(b, cr_pad)
     a, b = split(merge(a, b))
-    for i in range(len(STACK) - 1, -1, -1):
-        a, b = block_inverse(a, b, sd, f"stack.{i}.", STACK[i][0])
-    return inj_pad_inv(merge(a, b), 32 - in_channel)
+    for i in range(len(stack) - 1, -1, -1):
+        a, b = block_inverse(a, b, sd, f"stack.{i}.", stack[i][0])
+    return inj_pad_inv(merge(a, b), 2 * stack[0][1] - in_channel)
 
 
 # --------------------------------------------------------------------------- C-4 Cholesky

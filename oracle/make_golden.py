@@ -153,6 +153,39 @@ def main():
             g.update({f"x_{tag}": x, f"z_{tag}": z, f"zp_{tag}": zp, f"y_{tag}": y})
         save(f"net_{mode}", weights_seed=SEED_W, weights_checksum=sd_checksum(sd), frames_seed=5, **g)
 
+    # ------------------------------------------------------------------ other constructor arguments (models/RevResNet.py:166-201)
+    # the reference builds ANY (nBlocks, nStrides, nChannels, in_channel, mult, hidden_dim, sp_steps, kernel); two such nets, with
+    # seeded weights (non-zero biases) written into the fixture itself: A = three short stages, mult 2; B = two stages, 1-channel
+    # input, kernel 5, and a channel_reduction that really pads (16 -> 64 channels per half; the inverse drops those channels
+    # again, :157-160 — they return to zero on inverse(forward(x)), not on a perturbed code)
+    print("general architectures")
+    ga = {}
+    for tag, arch, hw in (("A", dict(nBlocks=[2, 3, 2], nStrides=[1, 2, 2], nChannels=[4, 16, 64], in_channel=3, mult=2,
+                                     hidden_dim=4, sp_steps=2, kernel=3), (16, 24)),
+                          ("B", dict(nBlocks=[1, 2], nStrides=[1, 2], nChannels=[4, 16], in_channel=1, mult=4, hidden_dim=16,
+                                     sp_steps=1, kernel=5), (12, 20))):
+        with contextlib.redirect_stdout(io.StringIO()):
+            gnet = ref_rev.RevResNet(**arch)
+        gsd = {}
+        for idx, (k, v) in enumerate(gnet.state_dict().items()):
+            rng = np.random.Generator(np.random.PCG64([4321, idx]))
+            bound = 1.0 / np.sqrt(v[0].numel()) if v.dim() == 4 else 0.05
+            gsd[k] = torch.from_numpy(rng.uniform(-bound, bound, size=tuple(v.shape)).astype(np.float32))
+        gnet.load_state_dict(gsd)
+        gnet.eval()
+        gx = rnd((2, arch["in_channel"]) + hw, 70, 0.0, 1.0)
+        gz = gnet(gx, forward=True)
+        check(f"arch {tag} forward", cpu_ref.revnet_forward(gx, gsd, arch["sp_steps"], arch), gz)
+        gzp = gz + 0.05 * rnd(tuple(gz.shape), 71)
+        gy = gnet(gzp, forward=False)
+        check(f"arch {tag} inverse", cpu_ref.revnet_inverse(gzp, gsd, arch["sp_steps"], arch["in_channel"], arch), gy)
+        rec = gnet(gz, forward=False)
+        print(f"  arch {tag}: z {tuple(gz.shape)}, |inverse(forward(x)) - x|max = {float((rec - gx).abs().max()):.3e}")
+        ga.update({f"{tag}_x": gx, f"{tag}_z": gz, f"{tag}_zp": gzp, f"{tag}_y": gy, f"{tag}_roundtrip": rec,
+                   f"{tag}_arch": np.array(repr(arch))})
+        ga.update({f"{tag}_w_{k}": v for k, v in gsd.items()})
+    save("net_general", **ga)
+
     # ------------------------------------------------------------------ cWCT (C-1 .. C-6)
     print("cwct")
     cw = ref_cwct.cWCT()

@@ -173,6 +173,48 @@ def test_network_vs_oracle_ragged(mode, shape, precision):
     assert_close(net(zp.cuda(), forward=False), yr, TIGHT, f"{mode} {shape} inverse")
 
 
+def test_general_architectures_golden(golden):
+    """RevResNet with the reference's OTHER constructor arguments (models/RevResNet.py:166-201) runs on the generic HIP ops
+    (csrc/generic.hip: exact fp32): two nets against goldens minted from the reference — A: three short stages, mult 2; B: two
+    stages, 1-channel input, kernel 5, a channel_reduction that pads 16 -> 64 channels per half — plus an architecture one step
+    off the published one against the oracle."""
+    import ast
+    from models.RevResNet import RevResNet
+    g = golden("net_general")
+    for tag in ("A", "B"):
+        arch = ast.literal_eval(str(g[f"{tag}_arch"]))
+        net = RevResNet(**arch)
+        net.load_state_dict({k[len(tag) + 3:]: T(g[k]) for k in g.files if k.startswith(f"{tag}_w_")})
+        net = net.to("cuda").eval()
+        x = T(g[f"{tag}_x"]).cuda()
+        z = net(x)
+        assert tuple(z.shape) == tuple(g[f"{tag}_z"].shape)
+        assert_close(z, T(g[f"{tag}_z"]), 2e-6, f"arch {tag} forward")
+        assert_close(net(T(g[f"{tag}_zp"]).cuda(), forward=False), T(g[f"{tag}_y"]), 2e-6, f"arch {tag} inverse")
+        assert_close(net(z, forward=False), x, 2e-6, f"arch {tag} inverse(forward(x))")
+        with pytest.raises(RuntimeError):
+            net(x[:, :, :-1])                                        # not a multiple of down_scale
+        with pytest.raises(NotImplementedError):
+            net.forward_u8(torch.zeros(1, 8, 8, 3, dtype=torch.uint8, device="cuda"))
+    # nBlocks = [2, 2, 2] of the published channel plan, with the cWCT in between, against the oracle
+    from models.cWCT import cWCT
+    arch = dict(nBlocks=[2, 2, 2], nStrides=[1, 2, 2], nChannels=[16, 64, 256], hidden_dim=16, sp_steps=2)
+    net = RevResNet(**arch).to("cuda").eval()
+    sd = {}
+    for idx, (k, v) in enumerate(net.state_dict().items()):
+        rng = np.random.Generator(np.random.PCG64([77, idx]))
+        bound = 1.0 / np.sqrt(v[0].numel()) if v.dim() == 4 else 0.05
+        sd[k] = T(rng.uniform(-bound, bound, size=tuple(v.shape)).astype(np.float32))
+    net.load_state_dict(sd)
+    xc, xs = synthetic_frames(1, 32, 48, seed=1), synthetic_frames(1, 24, 40, seed=2)
+    with torch.no_grad():
+        zc, zs = cpu_ref.revnet_forward(xc, sd, 2, arch), cpu_ref.revnet_forward(xs, sd, 2, arch)
+        zcs = cpu_ref.transfer(zc, zs)
+        ref = cpu_ref.revnet_inverse(zcs, sd, 2, 3, arch)
+        got = net(cWCT().transfer(net(xc.cuda()), net(xs.cuda())), forward=False)
+    assert_close(got, ref, 5e-5, "6-block net: stylised frame vs oracle")
+
+
 def test_bad_shapes_raise():
     net, _, _ = make_net("photo")
     with pytest.raises(RuntimeError):

@@ -92,10 +92,35 @@ def test_state_dict_contract():
         assert int(net.down_scale) == 4
         net.load_state_dict(synthetic_state_dict(1234, hd, sp))     # strict
         assert all(float(v.abs().sum()) > 0 for k, v in net.state_dict().items() if k.endswith("bias"))
+
+
+def test_general_constructor_arguments(golden):
+    """every argument of the reference's constructor (models/RevResNet.py:166-201) builds the reference's module tree: same
+    state_dict keys and shapes as the goldens' weights (minted from the reference for two non-default architectures); the
+    published architecture takes the tuned path, everything else the generic HIP ops; impossible stage sequences are refused"""
+    import ast
+    from models.RevResNet import RevResNet
+    g = golden("net_general")
+    for tag in ("A", "B"):
+        arch = ast.literal_eval(str(g[f"{tag}_arch"]))
+        net = RevResNet(**arch)
+        assert net._generic and int(net.down_scale) == int(np.prod(arch["nStrides"]))
+        want = {k[len(tag) + 3:]: g[k].shape for k in g.files if k.startswith(f"{tag}_w_")}
+        have = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        assert have == {k: tuple(v) for k, v in want.items()}
+        net.load_state_dict({k: torch.from_numpy(g[f"{tag}_w_{k}"]) for k in want})      # strict
+    assert not RevResNet()._generic and not RevResNet(hidden_dim=64, sp_steps=1)._generic
+    assert RevResNet(hidden_dim=32, sp_steps=2)._generic            # 512-channel channel_reduction: the generic path
+    assert RevResNet(nBlocks=[4, 4, 4])._generic and len(RevResNet(nBlocks=[4, 4, 4]).stack) == 12
+    assert RevResNet(nChannels=None, in_channel=4, nBlocks=[1, 1, 1], hidden_dim=8).in_ch == 8      # :179-180
+    with pytest.raises(ValueError):
+        RevResNet(nChannels=[16, 32, 128])                          # a stride-2 stage multiplies the channels by 4
+    with pytest.raises(ValueError):
+        RevResNet(nBlocks=[1, 1], nStrides=[1, 2, 2])
     with pytest.raises(NotImplementedError):
-        RevResNet(hidden_dim=32, sp_steps=2)
-    with pytest.raises(NotImplementedError):
-        RevResNet(nBlocks=[4, 4, 4])
+        RevResNet(kernel=4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        RevResNet(nBlocks=[1, 1, 1])(torch.zeros(1, 3, 16, 16))
 
 
 def test_no_cpu_fallback():

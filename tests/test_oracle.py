@@ -181,3 +181,23 @@ def test_cwct_use_double(golden):
         d32 = (cpu_ref.interpolation(c, [s1, s2], [0.7, 0.3], ac) - T(g[f"interp_ac{ac}"])).abs().max()
         assert float(d32) > 1e-3
     close(cpu_ref.transfer_seg(c, s1, g["cmask"], g["smask"], use_double=True), T(g["masked"]), 1e-6)
+
+
+def _general_case(g, tag):
+    import ast
+    arch = ast.literal_eval(str(g[f"{tag}_arch"]))
+    sd = {k[len(tag) + 3:]: T(g[k]) for k in g.files if k.startswith(f"{tag}_w_")}
+    return arch, sd
+
+
+def test_general_architectures(golden):
+    """the reference's other constructor arguments (models/RevResNet.py:166-201: nBlocks / nStrides / nChannels / in_channel / mult
+    / hidden_dim / sp_steps / kernel), goldens minted from the reference for two such nets (weights inside the fixture)"""
+    g = golden("net_general")
+    for tag in ("A", "B"):
+        arch, sd = _general_case(g, tag)
+        x = T(g[f"{tag}_x"])
+        with torch.no_grad():
+            close(cpu_ref.revnet_forward(x, sd, arch["sp_steps"], arch), T(g[f"{tag}_z"]))
+            close(cpu_ref.revnet_inverse(T(g[f"{tag}_zp"]), sd, arch["sp_steps"], arch["in_channel"], arch), T(g[f"{tag}_y"]))
+            close(cpu_ref.revnet_inverse(T(g[f"{tag}_z"]), sd, arch["sp_steps"], arch["in_channel"], arch), x, 5e-6)

@@ -39,6 +39,7 @@ EXPORTS = [
     "vst_normalize_block", "vst_range_flags", "vst_range_flags_async",
     "vst_cwct_stats_f64_workspace_bytes", "vst_cwct_stats_f64", "vst_cwct_factor_f64_workspace_bytes", "vst_cwct_factor_f64",
     "vst_cwct_apply_f64",
+    "vst_generic_conv", "vst_generic_squeeze", "vst_generic_unsqueeze", "vst_generic_copy_channels", "vst_generic_zero",
 ]
 RANGE_SATURATED = 1
 RANGE_WEIGHT = 2
@@ -172,6 +173,11 @@ def lib() -> C.CDLL:
         "vst_cwct_factor_f64_workspace_bytes": (sz, [i]),
         "vst_cwct_factor_f64": (i, [vp, C.POINTER(vp), C.POINTER(f), i, f, f, i, vp, vp, vp, vp]),
         "vst_cwct_apply_f64": (i, [vp, vp, i, lg, vp, vp, i, vp]),
+        "vst_generic_conv": (i, [vp, vp, vp, vp, f, i, vp, i, i, i, i, i, i, i, vp]),
+        "vst_generic_squeeze": (i, [vp, vp, i, i, i, i, vp]),
+        "vst_generic_unsqueeze": (i, [vp, vp, i, i, i, i, vp]),
+        "vst_generic_copy_channels": (i, [vp, vp, i, i, i, i, lg, i, i, vp]),
+        "vst_generic_zero": (i, [vp, sz, vp]),
         "vst_label_plan": (i, [vp, lg, vp, lg, vp, vp]),
         "vst_cwct_labels_workspace_bytes": (sz, [i, lg]),
         "vst_cwct_stats_labels": (i, [vp, i, lg, vp, vp, i, vp, vp, vp]),

@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from . import _lib
 from .code import PackedCode
-from .synth import STACK, CONV_IDX
+from .synth import CONV_IDX
 
 _PRECISIONS = _lib.PRECISIONS
 
@@ -63,12 +63,33 @@ class RevResNet(nn.Module):
     def __init__(self, nBlocks=[10, 10, 10], nStrides=[1, 2, 2], nChannels=[16, 64, 256], in_channel=3, mult=4,
                  hidden_dim=16, sp_steps=2, kernel=3, precision=None):
         super().__init__()
-        if (list(nBlocks), list(nStrides), list(nChannels or []), mult, kernel) != ([10, 10, 10], [1, 2, 2],
-                                                                                    [16, 64, 256], 4, 3):
-            raise NotImplementedError("the HIP path implements the published CAP-VSTNet architecture only "
-                                      "(nBlocks=[10,10,10], nStrides=[1,2,2], nChannels=[16,64,256], mult=4, kernel=3)")
-        if sp_steps not in (1, 2) or hidden_dim * 4 ** sp_steps != 256 or not (1 <= in_channel <= 16):
-            raise NotImplementedError("supported modes: (hidden_dim=16, sp_steps=2) and (hidden_dim=64, sp_steps=1)")
+        if not nChannels:                                    # models/RevResNet.py:179-180
+            nChannels = [in_channel * 2, in_channel * 2 * 4, in_channel * 2 * 4 ** 2]
+        nBlocks, nStrides, nChannels = list(nBlocks), list(nStrides), list(nChannels)
+        # The tuned kernels (conv.hip / conv3.hip, ZC layout, packed code) implement the published CAP-VSTNet architecture; every
+        # other constructor argument set the reference accepts runs on the generic HIP ops (csrc/generic.hip, vstnet_amd/generic.py):
+        # exact fp32, NCHW, complete but slow.
+        self._generic = not ((nBlocks, nStrides, nChannels, mult, kernel) == ([10, 10, 10], [1, 2, 2], [16, 64, 256], 4, 3)
+                             and sp_steps in (1, 2) and hidden_dim * 4 ** sp_steps == 256 and 1 <= in_channel <= 16)
+        if self._generic:
+            if not (len(nBlocks) == len(nStrides) == len(nChannels) and len(nBlocks) >= 1 and all(b >= 1 for b in nBlocks)):
+                raise ValueError("nBlocks, nStrides and nChannels need the same length and at least one block per stage")
+            if any(s not in (1, 2) for s in nStrides) or kernel % 2 == 0 or not (1 <= kernel <= 7):
+                raise NotImplementedError("generic path: strides in {1, 2}, odd kernel <= 7")
+            if nStrides[0] == 2:
+                raise NotImplementedError("generic path: the first stage must have stride 1 (as in the reference's defaults)")
+            prev = nChannels[0]
+            for i, (ch, st) in enumerate(zip(nChannels, nStrides)):
+                want = prev * 4 if st == 2 else prev
+                if ch != want:
+                    raise ValueError(f"stage {i}: {ch} channels cannot follow {prev} with stride {st} (a stride-2 block squeezes "
+                                     "its halves: x4 channels; a stride-1 stage keeps them)")
+                if ch % mult:
+                    raise ValueError(f"stage {i}: channel {ch} must be divisible by mult={mult}")
+                prev = ch
+            if hidden_dim * 4 ** sp_steps < nChannels[-1] or 2 * nChannels[0] < in_channel:
+                raise ValueError("channel_reduction pad = hidden_dim * 4**sp_steps - nChannels[-1] and the input pad "
+                                 "2 * nChannels[0] - in_channel must be >= 0")
         self.nBlocks = nBlocks
         self.in_channel = in_channel
         self.pad = 2 * nChannels[0] - in_channel
@@ -76,7 +97,11 @@ class RevResNet(nn.Module):
         self.down_scale = np.prod(np.array(nStrides))
         self.hidden_dim = hidden_dim
         self.sp_steps = sp_steps
-        self.stack = nn.ModuleList([residual_block(ch, stride, mult=mult, kernel=kernel) for stride, ch in STACK])
+        strides, chans = [], []
+        for ch, depth, st in zip(nChannels, nBlocks, nStrides):     # block_stack, models/RevResNet.py:190-201
+            strides += [st] + [1] * (depth - 1)
+            chans += [ch] * depth
+        self.stack = nn.ModuleList([residual_block(ch, st, mult=mult, kernel=kernel) for ch, st in zip(chans, strides)])
         self.channel_reduction = channel_reduction(nChannels[-1], hidden_dim, sp_steps=sp_steps, kernel=kernel)
         precision = precision or _lib.default_precision()
         if precision not in _PRECISIONS and precision != "auto":
@@ -294,9 +319,23 @@ class RevResNet(nn.Module):
             raise RuntimeError(f"{what}: expected [B,{channels},H,W], got {tuple(t.shape)}")
         return t.detach().to(torch.float32).contiguous()
 
+    def _generic_params_ready(self, device):
+        for p in self.parameters():
+            if p.device != device or p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError(f"generic-architecture RevResNet: parameters must be contiguous float32 on {device} "
+                                   f"(found {p.dtype} on {p.device}): call .float().to(device)")
+
     def _forward(self, x):
         """models/RevResNet.py:210-223."""
         x = self._check(x, self.in_channel, "RevResNet forward input")
+        if self._generic:
+            from . import generic
+            ds = int(self.down_scale)
+            if x.shape[2] % ds or x.shape[3] % ds:
+                raise RuntimeError(f"H and W must be multiples of down_scale = {ds} (got {x.shape[2]}x{x.shape[3]})")
+            self._generic_params_ready(x.device)
+            with torch.cuda.device(x.device), torch.no_grad():
+                return generic.forward(self, x)
         B, _, H, W = x.shape
         if H % 4 or W % 4 or H < 8 or W < 8:
             raise RuntimeError(f"H and W must be multiples of 4 and >= 8 (got {H}x{W})")
@@ -322,6 +361,14 @@ class RevResNet(nn.Module):
     def _inverse(self, z):
         """models/RevResNet.py:225-239."""
         s = self.sp_steps
+        if self._generic:
+            from . import generic
+            z = self._check(z, 2 * self.hidden_dim, "RevResNet inverse input")
+            if z.shape[2] % (2 ** s) or z.shape[3] % (2 ** s):
+                raise RuntimeError(f"code height / width must be multiples of {2 ** s}")
+            self._generic_params_ready(z.device)
+            with torch.cuda.device(z.device), torch.no_grad():
+                return generic.inverse(self, z)
         if isinstance(z, PackedCode) and z.sp_steps == s and not z.stale:
             return self._decode_packed(z, u8=False)
         z = self._check(z, 32 if s == 2 else 128, "RevResNet inverse input")
@@ -390,6 +437,8 @@ class RevResNet(nn.Module):
     def forward_u8(self, frames):
         """Encode uint8 HWC frames [B,H,W,3] (what PIL / cv2 hand over) — ToTensor's u8/255 scaling and the
         HWC->planes transpose happen inside the first boundary kernel (image_transfer.py:167, video_transfer.py:188)."""
+        if self._generic:
+            raise NotImplementedError("the uint8 frame edge exists for the published architecture only")
         if not frames.is_cuda or frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3:
             raise RuntimeError("forward_u8 expects a CUDA uint8 tensor [B,H,W,3]")
         if self.in_channel != 3:
@@ -421,6 +470,8 @@ class RevResNet(nn.Module):
         """Decode a code to uint8 HWC frames with the reference's quantisation: mul(255).clamp(0,255).byte()
         (truncation; image_transfer.py:217-218, video_transfer.py:212) fused into the last boundary kernel."""
         s = self.sp_steps
+        if self._generic:
+            raise NotImplementedError("the uint8 frame edge exists for the published architecture only")
         if isinstance(z, PackedCode) and z.sp_steps == s and not z.stale:
             return self._decode_packed(z, u8=True)
         z = self._check(z, 32 if s == 2 else 128, "RevResNet inverse input")
