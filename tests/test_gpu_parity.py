@@ -465,6 +465,38 @@ def test_video_transfer_script_sharded(tmp_path):
         assert np.array_equal(np.asarray(Image.open(os.path.join(outs[0], "00001.png"))), np.asarray(Image.open(single)))
 
 
+def test_video_transfer_gpus2_end_to_end(tmp_path):
+    """`video_transfer.py --gpus 2` for real (BASELINE config 5's launcher on hardware): two child processes — on a one-GPU box
+    they share the GPU, on a node each gets its own through HIP_VISIBLE_DEVICES — stylise contiguous shards of a masked clip,
+    the parent (which never touches the GPU) merges; the merged frames equal a single-process run bit for bit."""
+    import subprocess
+    import sys
+    from PIL import Image
+    from utils.utils import SEG_COLORS
+    fd = tmp_path / "clip"
+    fd.mkdir()
+    for i in range(5):
+        _png(fd / f"{i:03d}.png", 48, 64, 40 + i)
+    _png(tmp_path / "s.png", 40, 56, 6)
+    colours = np.array([c for c, _ in SEG_COLORS[:3]], dtype=np.uint8)
+    Image.fromarray(colours[synthetic_mask(48, 64, 3, seed=1, speck=False)]).save(tmp_path / "cseg.png")
+    Image.fromarray(colours[synthetic_mask(40, 56, 3, seed=2, speck=False)]).save(tmp_path / "sseg.png")
+    base = ["--video", str(fd), "--style", str(tmp_path / "s.png"), "--synthetic_weights", "--content_seg",
+            str(tmp_path / "cseg.png"), "--style_seg", str(tmp_path / "sseg.png"), "--frames_only"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video_transfer.py")]
+                       + base + ["--out_dir", str(tmp_path / "o2"), "--gpus", "2"], capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import video_transfer
+    single = video_transfer.main(base + ["--out_dir", str(tmp_path / "o1")])
+    multi = os.path.join(str(tmp_path / "o2"), os.path.basename(single))
+    names = sorted(os.listdir(single))
+    assert names == sorted(os.listdir(multi)) == ["%05d.png" % i for i in range(5)]
+    for n in names:
+        assert np.array_equal(np.asarray(Image.open(os.path.join(single, n))), np.asarray(Image.open(os.path.join(multi, n)))), n
+
+
 @pytest.mark.parametrize("precision", [None, "f16x2h"])
 def test_video_transfer_script_masked(tmp_path, precision):
     """video_transfer.py with --content_seg / --style_seg (config 5's call) at the product default precision and at f16x2h: the

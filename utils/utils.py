@@ -54,4 +54,4 @@ def load_segment(image_path, size=None):
 def to_tensor_u8(img):
     """PIL RGB image -> uint8 torch tensor [1,H,W,3] (the device side applies ToTensor's /255, RevResNet.forward_u8)."""
     import torch
-    return torch.from_numpy(np.ascontiguousarray(np.asarray(img.convert("RGB"), dtype=np.uint8)))[None]
+    return torch.from_numpy(np.array(img.convert("RGB"), dtype=np.uint8))[None]       # (a writable copy: PIL's buffer is read-only)

@@ -102,7 +102,8 @@ def launch_shards(args, argv):
             del base[i:i + 2]
     base = [a for a in base if not a.startswith("--gpus=") and not a.startswith("--shard=")]
     cmds = [[sys.executable, os.path.abspath(__file__)] + base + ["--shard", "%d/%d" % (r, n), "--frames_only"] for r in range(n)]
-    return launch_children(cmds, [rank_environment(r, n, visible_device=True) for r in range(n)])
+    n_dev = torch.cuda.device_count()                   # (counting devices does not initialise HIP; the parent never does)
+    return launch_children(cmds, [rank_environment(r, n, visible_device=True, n_devices=n_dev or None) for r in range(n)])
 
 
 def merge_outputs(frame_dir, n_frames, out_dir, name, fps, size):

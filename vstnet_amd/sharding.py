@@ -27,10 +27,12 @@ def rank_threads(world: int) -> int:
     return max(1, (os.cpu_count() or 1) // max(1, world))
 
 
-def rank_environment(rank: int, world: int, port: int | None = None, visible_device: bool = False) -> dict:
+def rank_environment(rank: int, world: int, port: int | None = None, visible_device: bool = False,
+                     n_devices: int | None = None) -> dict:
     """Environment of child `rank` of a self-launched node-local job: the torch.distributed.run variables (when a
     rendezvous port is given), a per-rank CPU thread cap, and — `visible_device` — HIP_VISIBLE_DEVICES so that the child
-    sees exactly its own GPU as device 0 (children that need no rendezvous, e.g. video shards)."""
+    sees exactly its own GPU as device 0 (children that need no rendezvous, e.g. video shards).  n_devices (optional): the
+    node's GPU count; with fewer GPUs than ranks (a rehearsal on a one-GPU box) rank r shares GPU r % n_devices."""
     env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     n = str(rank_threads(world))
@@ -39,7 +41,7 @@ def rank_environment(rank: int, world: int, port: int | None = None, visible_dev
     if port is not None:
         env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if visible_device:
-        env["HIP_VISIBLE_DEVICES"] = str(rank)
+        env["HIP_VISIBLE_DEVICES"] = str(rank % n_devices if n_devices else rank)
         env["LOCAL_RANK"] = "0"
     return env
 
