@@ -310,3 +310,11 @@ def test_packed_weights_follow_parameter_edits():
     holder = torch.nn.Sequential(net)
     holder.load_state_dict(holder.state_dict())           # recurses without calling net.load_state_dict
     assert net._param_versions(convs) != v1 and net._packed is None
+    # writes through `.data` are invisible to the key (p.data is another tensor object with its own version counter, same
+    # storage): the documented remedy is refresh_weights()
+    v2 = net._param_versions(convs)
+    net._packed = ("sentinel",)
+    net.stack[0].conv[1].weight.data.copy_(torch.zeros_like(net.stack[0].conv[1].weight))
+    assert net._param_versions(convs) == v2 and net._packed is not None
+    net.refresh_weights()
+    assert net._packed is None

@@ -61,10 +61,23 @@ def build_parser():
     return p
 
 
+class FrameDir:
+    """A directory of frames as a lazy sequence: a frame is decoded when it is asked for, so a shard (one of N processes) holds
+    only its own frames and the parent of a multi-GPU run only the first one (for the writer size)."""
+
+    def __init__(self, path):
+        self.files = sorted(os.path.join(path, f) for f in os.listdir(path) if f.lower().endswith(IMG_EXT))
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, i):
+        return Image.open(self.files[i]).convert('RGB')
+
+
 def read_frames(path):
     if os.path.isdir(path):
-        files = sorted(os.path.join(path, f) for f in os.listdir(path) if f.lower().endswith(IMG_EXT))
-        return [Image.open(f).convert('RGB') for f in files]
+        return FrameDir(path)
     try:
         import cv2
     except ImportError as e:
