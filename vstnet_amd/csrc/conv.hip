@@ -43,6 +43,9 @@ struct ConvArgs {
 #ifndef VST_XCD_REMAP
 #define VST_XCD_REMAP 1
 #endif
+#ifndef VST_PIPE_NO_DEFER
+#define VST_PIPE_NO_DEFER 0          // 1: conv_pipe_kernel stores every slice at its end (the form before round 3; A/B builds)
+#endif
 #ifdef VST_TRACE
 // Diagnostic build only (-DVST_TRACE=1: conv_pair_kernel, 2: conv_mfma_kernel): every workgroup of the LAST traced launch
 // leaves {start, end (100 MHz ticks), HW_ID, XCC_ID} here; tools/trace_grid.py reads them back through vst_trace_dump.
@@ -895,6 +898,14 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const ConvArgs a) {
     const int oy0 = ty0 + wave * C::MR;
     float4 bias[4], old[C::MR][4];
     const bool full_tile = ty0 + 16 <= a.Hout && tx0 + 16 <= a.Wout;    // uniform: interior tiles skip all predicates
+    // Kernels that loop several 64-channel output slices (the 64 -> 256 conv: four) DEFER a slice's stores: at the slice's end
+    // the results are formed in place in `old` (old + sign * (acc + bias)), and the eight float4 stores per lane go out one per
+    // k-step during the next slice's first chunk, between its MFMAs - all eight waves used to issue them together behind the
+    // slice's last MFMA, in front of the stage barrier (a timing-only build without three of the four epilogues:
+    // 59.5 -> 49.5 us).  `old` is free for that long: the next slice loads its own old values at its last stage.
+    constexpr bool DEFER = OUT_STATE && C::NCOT > 1 && C::NCHUNK == 2 && !VST_PIPE_NO_DEFER;
+    bool pending = false;                                    // uniform: `old` holds a finished slice whose stores are still due
+    int pend_cot = 0;
 
 #pragma unroll 1
     for (int q0 = 0; q0 < Q; q0 += 2) {
@@ -915,8 +926,13 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const ConvArgs a) {
                 const int qn = dy == 2 ? q + 1 : q, dyn = (dy + 1) % 3;
                 if (qn < C::NCHUNK - 1) LOAD_A(ra[cur], qn + 1, dyn);
             }
-            if (dy == 0 && chunk == 0) load_bias<COUT, 4>(a, cot * 64 + 4 * kg, bias);
-            if (OUT_STATE && dy == 2 && last_chunk) {     // old state values of this output slice, used after the MFMAs
+            // (bias: a few cached bytes.  The multi-slice kernels fetch it at the slice's LAST stage top - live for one stage
+            // instead of six - which pays for the longer-lived old values below)
+            if (DEFER ? (dy == 2 && last_chunk) : (dy == 0 && chunk == 0)) load_bias<COUT, 4>(a, cot * 64 + 4 * kg, bias);
+            // old state values of this output slice, used after its last MFMA.  (Fetching them one or two stages earlier - the
+            // DEFER kernels' `old` registers are free by then - was measured and is WORSE, 60.1 / 60.4 against 58.4 us: vmcnt is
+            // in-order, so the next stage's wait for its weights also waits for these older, slower loads.)
+            if (OUT_STATE && dy == 2 && last_chunk && (!(VST_ABLATE & 4) || cot == C::NCOT - 1)) {
                 if (full_tile) load_old<COUT, C::MR, 4, true>(a, out_img, oy0, tx0 + lrow, cot * 64 + 4 * kg, old);
                 else load_old<COUT, C::MR, 4, false>(a, out_img, oy0, tx0 + lrow, cot * 64 + 4 * kg, old);
             }
@@ -937,6 +953,14 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const ConvArgs a) {
             for (int k3 = 0; k3 < 3; ++k3) {
                 __builtin_amdgcn_sched_barrier(0);            // reads of k-step k3+1 stay ahead of the MFMAs of k3
                 if (k3 < 2 && !(VST_ABLATE & 1)) read_frags(fr[(k3 + 1) & 1], Ab, Bb, k3 + 1);
+                if constexpr (DEFER) {
+                    if (qq == 0 && dy * 3 + k3 < C::MR * 4 && pending) {       // unit dy*3+k3 = (m, n) of the previous slice
+                        const int unit = dy * 3 + k3, m_ = unit >> 2, n_ = unit & 3;
+                        float4* p_ = full_tile ? out_ptr<COUT, OUT_STATE, true>(a, out_img, oy0 + m_, tx0 + lrow, pend_cot * 64 + 4 * kg + n_ * 16)
+                                               : out_ptr<COUT, OUT_STATE, false>(a, out_img, oy0 + m_, tx0 + lrow, pend_cot * 64 + 4 * kg + n_ * 16);
+                        if (full_tile || p_) *p_ = old[m_][n_];
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 const Frags& f = fr[(VST_ABLATE & 1) ? 0 : (k3 & 1)];
 #pragma unroll
@@ -946,13 +970,33 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const ConvArgs a) {
             }
 
             // ---- output tile of this 64-channel slice ------------------------------------------------------------
-            if (dy == 2 && last_chunk) {
+            if (DEFER && dy == 2 && last_chunk && cot != C::NCOT - 1 && !(VST_ABLATE & 4)) {
+#pragma unroll
+                for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        const float4 o = old[m][n];
+                        old[m][n] = make_float4(o.x + a.sign * (acc[m][n][0] + bias[n].x), o.y + a.sign * (acc[m][n][1] + bias[n].y),
+                                                o.z + a.sign * (acc[m][n][2] + bias[n].z), o.w + a.sign * (acc[m][n][3] + bias[n].w));
+                        acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                pending = true;
+                pend_cot = cot;
+            } else
+            if (dy == 2 && last_chunk && (!(VST_ABLATE & 4) || cot == C::NCOT - 1)) {   // (ablation 4: only the last slice's epilogue)
                 if (full_tile) store_tile<COUT, OUT_STATE, C::MR, 4, true>(a, out_img, oy0, tx0 + lrow, cot * 64 + 4 * kg, acc, bias, old);
                 else store_tile<COUT, OUT_STATE, C::MR, 4, false>(a, out_img, oy0, tx0 + lrow, cot * 64 + 4 * kg, acc, bias, old);
 #pragma unroll
                 for (int m = 0; m < C::MR; ++m)
 #pragma unroll
                     for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (DEFER && qq == 0 && dy == 2) pending = false;       // the previous slice's eight units went out in this chunk
+            if ((VST_ABLATE & 4) && dy == 2 && last_chunk && cot != C::NCOT - 1) {   // timing-only: a slice without its epilogue
+#pragma unroll
+                for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) asm volatile("" : "+v"(acc[m][n]));
             }
             __syncthreads();
         }
