@@ -43,6 +43,9 @@ struct ConvArgs {
 #ifndef VST_XCD_REMAP
 #define VST_XCD_REMAP 1
 #endif
+#ifndef VST_PIPE_OLD_SPREAD
+#define VST_PIPE_OLD_SPREAD 1        // conv_pipe_kernel (multi-slice form): old state values fetched one unit per k-step (see there)
+#endif
 #ifndef VST_PIPE_NO_DEFER
 #define VST_PIPE_NO_DEFER 0          // 1: conv_pipe_kernel stores every slice at its end (the form before round 3; A/B builds)
 #endif
@@ -932,7 +935,11 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const ConvArgs a) {
             // old state values of this output slice, used after its last MFMA.  (Fetching them one or two stages earlier - the
             // DEFER kernels' `old` registers are free by then - was measured and is WORSE, 60.1 / 60.4 against 58.4 us: vmcnt is
             // in-order, so the next stage's wait for its weights also waits for these older, slower loads.)
-            if (OUT_STATE && dy == 2 && last_chunk && (!(VST_ABLATE & 4) || cot == C::NCOT - 1)) {
+            // The DEFER kernels fetch them SPREAD instead: unit (m, n) right after the previous slice's unit (m, n) has been
+            // stored from the same registers, one float4 per lane and k-step over the slice's first chunk - the launch's 256
+            // workgroups run in lockstep, and a whole slice's old values at one stage top are a 16 MB burst (~3 us of HBM time
+            // in front of a 1.3 us stage); a few small loads per stage, a stage or more old when used, stall nobody.
+            if (OUT_STATE && !(DEFER && VST_PIPE_OLD_SPREAD) && dy == 2 && last_chunk && (!(VST_ABLATE & 4) || cot == C::NCOT - 1)) {
                 if (full_tile) load_old<COUT, C::MR, 4, true>(a, out_img, oy0, tx0 + lrow, cot * 64 + 4 * kg, old);
                 else load_old<COUT, C::MR, 4, false>(a, out_img, oy0, tx0 + lrow, cot * 64 + 4 * kg, old);
             }
@@ -954,11 +961,18 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const ConvArgs a) {
                 __builtin_amdgcn_sched_barrier(0);            // reads of k-step k3+1 stay ahead of the MFMAs of k3
                 if (k3 < 2 && !(VST_ABLATE & 1)) read_frags(fr[(k3 + 1) & 1], Ab, Bb, k3 + 1);
                 if constexpr (DEFER) {
-                    if (qq == 0 && dy * 3 + k3 < C::MR * 4 && pending) {       // unit dy*3+k3 = (m, n) of the previous slice
+                    if (qq == 0 && dy * 3 + k3 < C::MR * 4) {                  // unit dy*3+k3 = (m, n)
                         const int unit = dy * 3 + k3, m_ = unit >> 2, n_ = unit & 3;
-                        float4* p_ = full_tile ? out_ptr<COUT, OUT_STATE, true>(a, out_img, oy0 + m_, tx0 + lrow, pend_cot * 64 + 4 * kg + n_ * 16)
-                                               : out_ptr<COUT, OUT_STATE, false>(a, out_img, oy0 + m_, tx0 + lrow, pend_cot * 64 + 4 * kg + n_ * 16);
-                        if (full_tile || p_) *p_ = old[m_][n_];
+                        if (pending) {                                         // ... of the previous slice: its deferred store
+                            float4* p_ = full_tile ? out_ptr<COUT, OUT_STATE, true>(a, out_img, oy0 + m_, tx0 + lrow, pend_cot * 64 + 4 * kg + n_ * 16)
+                                                   : out_ptr<COUT, OUT_STATE, false>(a, out_img, oy0 + m_, tx0 + lrow, pend_cot * 64 + 4 * kg + n_ * 16);
+                            if (full_tile || p_) *p_ = old[m_][n_];
+                        }
+                        if (VST_PIPE_OLD_SPREAD) {                             // ... of this slice: its old state value, see below
+                            const float4* q_ = full_tile ? out_ptr<COUT, OUT_STATE, true>(a, out_img, oy0 + m_, tx0 + lrow, cot * 64 + 4 * kg + n_ * 16)
+                                                         : out_ptr<COUT, OUT_STATE, false>(a, out_img, oy0 + m_, tx0 + lrow, cot * 64 + 4 * kg + n_ * 16);
+                            old[m_][n_] = (full_tile || q_) ? *q_ : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
