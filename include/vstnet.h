@@ -321,6 +321,20 @@ int vst_profile_end(double* total_ms, int* launches);
 /* per-id totals of a VST_KERNEL_ALL (or single-id) session: ids[i], ms[i], launches[i] for i < *n_ids <= cap */
 int vst_profile_end_table(int* ids, double* ms, int* launches, int cap, int* n_ids);
 
+/* ---------------------------------------------------------------------------------------------
+ * Process-wide tuning options (atomic; may be set at any time, a launch reads them when it is enqueued).
+ *   VST_OPT_STAGE3_LEAN  1: the 256-channel convs of VST_PREC_BF16X3 (residual_block.conv of models/RevResNet.py:79-88 at
+ *                        C = 256) run as half-CU workgroups (4 waves, 8 x 16 pixel tiles, 96 KB of LDS, <= 256 VGPRs) so that
+ *                        the HBM-bound 16- / 64-channel kernels of ANOTHER frame on another stream share their CUs - for callers
+ *                        that keep several frames in flight (video_transfer.py:160-214's loop run on HIP streams);
+ *                        0: 8 waves on 16 x 16 tiles, one workgroup per CU (best for one frame at a time).  Results are
+ *                        bit-identical.  Initial value: environment variable VST_LEAN (0 / 1), else VST_LEAN_DEFAULT.
+ * vst_set_option returns VST_E_ARG for an unknown option, vst_get_option the value (or VST_E_ARG).
+ * ------------------------------------------------------------------------------------------- */
+#define VST_OPT_STAGE3_LEAN 1
+int vst_set_option(int option, int value);
+int vst_get_option(int option);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

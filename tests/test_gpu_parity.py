@@ -847,24 +847,56 @@ def test_full_size_config3_art_batch4(precision, tol_z, tol_y, tol_rt):
         assert torch.isfinite(sty).all() and sty.shape == x.shape
 
 
+# Large frames against the ORACLE, both ends of the image and both directions (VERDICT r3 "what's weak" 1): the oracle runs on
+# a CROP x CROP crop that shares the image's real top-left (or bottom-right) border, and the CORNER x CORNER corner next to that
+# border is compared.  A pass reaches at most 10*3*1 + 10*3*2 + 12*3*4 = 234 full-resolution pixels (30 + 2 blocks x 3 convs,
+# one pixel each at the block's resolution), less than the CROP - CORNER = 256 pixels between the corner and the crop's
+# artificial borders, so the corner sees exactly what it sees in the full frame - including the ReflectionPad at the real
+# border (models/RevResNet.py:79-88), the ragged last tile row / column and the far tiles' addresses.
+CROP, CORNER = 768, 512
+
+
+def _corner(H, W, which):
+    """(crop slices in the frame, corner slices inside the crop, corner slices in the frame)"""
+    if which == "tl":
+        return (slice(0, CROP), slice(0, CROP)), (slice(0, CORNER), slice(0, CORNER)), (slice(0, CORNER), slice(0, CORNER))
+    return ((slice(H - CROP, H), slice(W - CROP, W)), (slice(CROP - CORNER, CROP), slice(CROP - CORNER, CROP)),
+            (slice(H - CORNER, H), slice(W - CORNER, W)))
+
+
+def check_corners_vs_oracle(x_cpu, z_c, z_cs, sty, sd, sp, tol_z, tol_y, what):
+    """encode: the oracle's code of the crop of x vs the GPU's code; decode: the oracle's revnet_inverse (models/RevResNet.py:
+    225-239) of the crop of the GPU's OWN transferred code vs the GPU's stylised frame - top-left and bottom-right."""
+    H, W = x_cpu.shape[2:]
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        for which in ("tl", "br"):
+            (cy, cx), (iy, ix), (fy, fx) = _corner(H, W, which)
+            z_or = cpu_ref.revnet_forward(x_cpu[:, :, cy, cx].contiguous(), sd, sp)
+            assert_close(z_c[:, :, fy, fx], z_or[:, :, iy, ix], tol_z, f"{what}: code, {which} corner vs oracle")
+            y_or = cpu_ref.revnet_inverse(z_cs[:, :, cy, cx].float().cpu().contiguous(), sd, sp)
+            assert_close(sty[:, :, fy, fx], y_or[:, :, iy, ix], tol_y, f"{what}: decoded frame, {which} corner vs oracle")
+
+
 @pytest.mark.parametrize("precision,tol_z,tol_y,tol_rt", CFG_MODES)
 def test_full_size_config4_4096(precision, tol_z, tol_y, tol_rt):
     """config 4: one 4096x4096 photorealistic image on one GPU (2 GiB of state per half; the pass runs in sub-batches
-    sized for the Infinity Cache).  The code's top-left 512x512 against the ORACLE run on the top-left 640x640 crop (the
-    receptive field of 30 blocks x 3 convs is 90 px < 128: that corner of the code does not see beyond the crop), then
-    properties: invertibility, crop consistency on the GPU, style moments."""
+    sized for the Infinity Cache).  Code AND decoded frame against the ORACLE at the top-left and the bottom-right corner
+    (check_corners_vs_oracle: the far tiles, byte offsets near 2^30), then properties: invertibility, crop consistency on the
+    GPU, style moments."""
     from models.cWCT import cWCT
     net, sd, sp = make_net("photo", precision)
     cw = cWCT(precision=precision)
     x_cpu = synthetic_frames(1, 4096, 4096, seed=11)
-    with torch.no_grad():
-        torch.set_num_threads(16)
-        z_or = cpu_ref.revnet_forward(x_cpu[:, :, :640, :640].contiguous(), sd, sp)[:, :, :512, :512]
     x = x_cpu.cuda()
     xs = synthetic_frames(1, 1024, 1024, seed=1).cuda()
     with torch.no_grad():
         z = net(x)
-        assert_close(z[:, :, :512, :512], z_or, tol_z, f"4096x4096 code, 512x512 corner vs oracle ({precision})")
+        zcs_ = cw.transfer(z, net(xs))
+        sty_ = net(zcs_, forward=False)
+        check_corners_vs_oracle(x_cpu, z, zcs_, sty_, sd, sp, tol_z, TIGHT if precision == "bf16x3" else tol_y,
+                                f"4096x4096 ({precision})")
+        del zcs_, sty_
         assert float((net(z, forward=False) - x).abs().max()) < tol_rt
         zc = net(x[:, :, :1024, :1024].contiguous())
         d = (z[:, :, :512, :512] - zc[:, :, :512, :512]).abs().max()
@@ -905,15 +937,15 @@ def test_full_size_config5_1080p_masked(kind, precision):
         assert float((_cov(a) - _cov(b)).abs().max() / _cov(b).abs().max()) < 2e-4, label
     speck = cmt == 5
     assert int(speck.sum()) == 6 and torch.equal(a_all[:, speck], c_all[:, speck])
-    # the encode against the ORACLE on the top-left 640x640 crop (512x512 corner of the code: receptive field 90 px < 128),
-    # the masked cWCT against the oracle's transfer_seg fed with the same codes, and the route video_transfer.py takes
+    # the encode and the decode against the ORACLE at both corners (check_corners_vs_oracle), the masked cWCT against the
+    # oracle's transfer_seg fed with the same codes, and the route video_transfer.py takes
     # (learnt slot count -> per-label maps on the packed rows, applied inside the uint8 decode) against the dense route
     tol_z = TIGHT if precision == "bf16x3" else 2.5e-4
     with torch.no_grad():
         torch.set_num_threads(16)
         x_cpu = x.cpu()
-        z_or = cpu_ref.revnet_forward(x_cpu[:, :, :640, :640].contiguous(), sd, sp)[:, :, :512, :512]
-        assert_close(zc0[:, :, :512, :512], z_or, tol_z, f"1080p code corner vs oracle ({precision})")
+        # 1080 rows = 270 quarter-resolution rows = 16 tiles + a 14-row ragged tile: the bottom-right corner covers it
+        check_corners_vs_oracle(x_cpu, zc0, zcs, net(zcs, forward=False), sd, sp, tol_z, tol_z, f"1080p {kind} ({precision})")
         ref = cpu_ref.transfer_seg(zc0.cpu(), zs.cpu(), cm, sm)
         assert_close(zcs, ref, 2e-4, f"1080p masked cWCT vs oracle ({kind})", tol_max=TOL)
         plan = cw.bind_style(cw.learn_slots(cw.plan_masks(cm, sm, zc.shape, zs.shape, zc.device)), zs)
@@ -923,6 +955,33 @@ def test_full_size_config5_1080p_masked(kind, precision):
         u8_packed, u8_dense = net.inverse_u8(t), net.inverse_u8(zcs)
         dd = (u8_packed.int() - u8_dense.int()).abs()
         assert int(dd.max()) <= 1 and float((dd > 0).float().mean()) < (1e-3 if precision == "bf16x3" else 2e-2)
+
+
+@pytest.mark.parametrize("shape", [(1024, 1024), (200, 280), (72, 40)])
+def test_stage3_lean_option_is_bit_identical(shape):
+    """VST_OPT_STAGE3_LEAN (vstnet.h): the 256-channel convs of bf16x3 as half-CU workgroups (4 waves, 8 x 16 tiles) give the
+    same bits as the 8-wave form (same MFMA order per accumulator) - full size, ragged tiles, a frame smaller than a tile."""
+    from models.cWCT import cWCT
+    from vstnet_amd import _lib
+    net, sd, sp = make_net("photo", "bf16x3")
+    cw = cWCT(precision="bf16x3")
+    h, w = shape
+    xc, xs = synthetic_frames(1, h, w, seed=0).cuda(), synthetic_frames(1, h, w, seed=1).cuda()
+    res = []
+    assert _lib.get_option(_lib.OPT_STAGE3_LEAN) in (0, 1)
+    before = _lib.get_option(_lib.OPT_STAGE3_LEAN)
+    try:
+        with torch.no_grad():
+            for lean in (0, 1):
+                _lib.set_option(_lib.OPT_STAGE3_LEAN, lean)
+                zc = net(xc)
+                sty = net(cw.transfer(zc, net(xs)), forward=False)
+                res.append((torch.as_tensor(zc).float().clone(), sty.clone()))
+    finally:
+        _lib.set_option(_lib.OPT_STAGE3_LEAN, before)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    with pytest.raises(_lib.VstError):
+        _lib.set_option(99, 1)
 
 
 # ------------------------------------------------------------------------------------------- full size vs the oracle itself

@@ -40,7 +40,9 @@ EXPORTS = [
     "vst_cwct_stats_f64_workspace_bytes", "vst_cwct_stats_f64", "vst_cwct_factor_f64_workspace_bytes", "vst_cwct_factor_f64",
     "vst_cwct_apply_f64",
     "vst_generic_conv", "vst_generic_squeeze", "vst_generic_unsqueeze", "vst_generic_copy_channels", "vst_generic_zero",
+    "vst_set_option", "vst_get_option",
 ]
+OPT_STAGE3_LEAN = 1
 RANGE_SATURATED = 1
 RANGE_WEIGHT = 2
 
@@ -198,6 +200,8 @@ def lib() -> C.CDLL:
         "vst_cwct_apply_labels_code": (i, [vp, vp, i, i, vp, vp, vp, i, vp]),
         "vst_revnet_decode_labels": (i, [C.POINTER(NetWeights), vp, vp, vp, vp, i, vp, vp, i, i, i, i, vp]),
         "vst_revnet_decode_labels_u8": (i, [C.POINTER(NetWeights), vp, vp, vp, vp, i, vp, vp, i, i, i, vp]),
+        "vst_set_option": (i, [i, i]),
+        "vst_get_option": (i, [i]),
         "vst_profile_begin": (i, [i, i]),
         "vst_profile_end": (i, [C.POINTER(C.c_double), C.POINTER(i)]),
         "vst_profile_end_table": (i, [C.POINTER(i), C.POINTER(C.c_double), C.POINTER(i), i, C.POINTER(i)]),
@@ -225,6 +229,18 @@ def profile_table(run, max_records: int = 4096):
         ids, ms, cnt, n = (C.c_int * 64)(), (C.c_double * 64)(), (C.c_int * 64)(), C.c_int(0)
         check(L.vst_profile_end_table(ids, ms, cnt, 64, C.byref(n)), "vst_profile_end_table")
     return {ids[k]: (ms[k], cnt[k]) for k in range(n.value)}
+
+
+def set_option(option: int, value: int) -> None:
+    """Process-wide tuning option of include/vstnet.h (VST_OPT_*)."""
+    check(lib().vst_set_option(option, int(value)), "vst_set_option")
+
+
+def get_option(option: int) -> int:
+    v = lib().vst_get_option(option)
+    if v < 0:
+        check(v, "vst_get_option")
+    return v
 
 
 def kernel_id(cin: int, cout: int, stride: int) -> int:

@@ -15,6 +15,7 @@
 // 16-byte slots (bank-conflict-free ds_read_b128 for every tap shift); weights are pre-packed in
 // fragment order (layout.hip) and copied straight into LDS.
 #include <mutex>
+#include <stdlib.h>
 #include "common.h"
 
 #ifndef VST_ABLATE
@@ -36,6 +37,7 @@ struct ConvArgs {
     const float* bias1;
     unsigned char* out_sp;               // OUT_SP: the output goes to split fp16 planes (common.h) instead of `out`
     size_t out_sp_img_bytes;
+    unsigned trace_base;                 // -DVST_TRACE=3 builds: first record of this launch in the trace buffer
 };
 
 // Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2.  Give XCD k the contiguous
@@ -50,31 +52,62 @@ struct ConvArgs {
 #define VST_PIPE_NO_DEFER 0          // 1: conv_pipe_kernel stores every slice at its end (the form before round 3; A/B builds)
 #endif
 #ifdef VST_TRACE
-// Diagnostic build only (-DVST_TRACE=1: conv_pair_kernel, 2: conv_mfma_kernel): every workgroup of the LAST traced launch
+// Diagnostic builds only (-DVST_TRACE=1: conv_pair_kernel, 2: conv_mfma_kernel): every workgroup of the LAST traced launch
 // leaves {start, end (100 MHz ticks), HW_ID, XCC_ID} here; tools/trace_grid.py reads them back through vst_trace_dump.
+// -DVST_TRACE=3: EVERY workgroup of EVERY conv launch (classes 1, 2, 4 = conv_pipe_kernel) appends
+// {start, end, HW_ID | XCC_ID << 32, class | Cin << 8 | Cout << 20 | blockIdx << 32} to a caller-provided buffer
+// (vst_trace_set; tools/trace_cu.py): which kernels of which streams were resident on which CU, when.
 __device__ unsigned long long vst_trace_buf[4 * 16384];
+__device__ unsigned long long* vst_trace_ptr;
+__device__ unsigned vst_trace_cap;
+static std::atomic<unsigned> vst_trace_host_n{0};     // next free record (launch sites reserve one per workgroup)
+#define VST_TRACE_RESERVE(t_, grid_) (t_).trace_base = vst_trace_host_n.fetch_add((unsigned)(grid_));
 #define VST_TRACE_BEGIN(which)                                                                                  \
     const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();   /* scalar: no VGPR is held for it */
-#define VST_TRACE_END(which)                                                                                    \
-    if (VST_TRACE == (which)) {                                                                                 \
+#define VST_TRACE_END_(which, cin_, cout_)                                                                      \
+    if (VST_TRACE == (which) || VST_TRACE == 3) {                                                               \
         __builtin_amdgcn_s_waitcnt(0);                                                                          \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
-        if (threadIdx.x == 0 && blockIdx.x < 16384) {                                                           \
+        if (threadIdx.x == 0 && (VST_TRACE == 3 || blockIdx.x < 16384)) {                                       \
             unsigned hw, xcc;                                                                                   \
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                    \
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                                  \
-            vst_trace_buf[4 * blockIdx.x + 0] = trace_t0;                                                       \
-            vst_trace_buf[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();                               \
-            vst_trace_buf[4 * blockIdx.x + 2] = hw;                                                             \
-            vst_trace_buf[4 * blockIdx.x + 3] = xcc;                                                            \
+            if (VST_TRACE == 3) {                                                                               \
+                const unsigned i_ = a.trace_base + blockIdx.x;                                                  \
+                if (vst_trace_ptr && i_ < vst_trace_cap) {                                                      \
+                    unsigned long long* r_ = vst_trace_ptr + 4 * (size_t)i_;                                    \
+                    r_[0] = trace_t0;                                                                           \
+                    r_[1] = __builtin_amdgcn_s_memrealtime();                                                   \
+                    r_[2] = hw | ((unsigned long long)xcc << 32);                                               \
+                    r_[3] = (which) | ((cin_) << 8) | ((cout_) << 20) | ((unsigned long long)blockIdx.x << 32); \
+                }                                                                                               \
+            } else {                                                                                            \
+                vst_trace_buf[4 * blockIdx.x + 0] = trace_t0;                                                   \
+                vst_trace_buf[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();                           \
+                vst_trace_buf[4 * blockIdx.x + 2] = hw;                                                         \
+                vst_trace_buf[4 * blockIdx.x + 3] = xcc;                                                        \
+            }                                                                                                   \
         }                                                                                                       \
     }
-extern "C" int vst_trace_dump(unsigned long long* host, int n_wg) {
+#define VST_TRACE_END(which) VST_TRACE_END_(which, 0, 0)
+extern "C" __attribute__((visibility("default"))) int vst_trace_dump(unsigned long long* host, int n_wg) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vst_trace_buf), sizeof(unsigned long long) * 4 * (size_t)n_wg);
 }
+// append mode: records go to `dev_buf` (cap records of 4 x u64); returns the number of records written so far through *n
+extern "C" __attribute__((visibility("default"))) int vst_trace_set(unsigned long long* dev_buf, unsigned cap) {
+    const unsigned zero = 0;
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(vst_trace_ptr), &dev_buf, sizeof(dev_buf));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(vst_trace_cap), &cap, sizeof(cap));
+    (void)zero;
+    vst_trace_host_n.store(0);
+    return (int)e;
+}
+extern "C" __attribute__((visibility("default"))) int vst_trace_count(unsigned* n) { *n = vst_trace_host_n.load(); return 0; }
 #else
 #define VST_TRACE_BEGIN(which)
 #define VST_TRACE_END(which)
+#define VST_TRACE_END_(which, cin_, cout_)
+#define VST_TRACE_RESERVE(t_, grid_)
 #endif
 
 __device__ __forceinline__ bool xcd_tile(const ConvArgs& a, int& bx, int& by, int& bz) {
@@ -446,14 +479,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                 *(f16x4*)(o16 + ((size_t)oy * a.Wout + ox) * COUT + co) = h;
             }
         vst_note_range(range_amax);
-        VST_TRACE_END(2)
+        VST_TRACE_END_(2, CIN, COUT)
         return;
     }
     if constexpr (TERMS == 2) vst_note_range(range_amax);
     if (OUT_STATE && !EARLY_OLD) fetch_old();
     if (interior) store_tile<COUT, OUT_STATE, C::MR, C::NB, true>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, acc, bias, old);
     else store_tile<COUT, OUT_STATE, C::MR, C::NB>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, co0 + 4 * kg, acc, bias, old);
-    VST_TRACE_END(2)
+    VST_TRACE_END_(2, CIN, COUT)
 }
 
 // ---- conv.4 + conv.7 of one stage-1 / stage-2 coupling block in one launch -----------------------------------------
@@ -756,7 +789,7 @@ __global__ __launch_bounds__(256, (MID == 16 && TERMS == 2) ? 3 : 1) void conv_p
 #undef PAIR_FETCH_OLD
     if (interior) store_tile<CH, true, C::MR, C::NB, true>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, 4 * kg, acc, bias, old);
     else store_tile<CH, true, C::MR, C::NB>(a, out_img, ty0 + wave * C::MR, tx0 + lrow, 4 * kg, acc, bias, old);
-    VST_TRACE_END(1)
+    VST_TRACE_END_(1, MID, CH)
 }
 
 // ---- pipelined kernel for the MFMA-bound shapes: CIN in {64,256}, COUT in {64,256}, stride 1 --------
@@ -765,17 +798,21 @@ __global__ __launch_bounds__(256, (MID == 16 && TERMS == 2) ? 3 : 1) void conv_p
 // third of the next chunk's activations into registers and writes them to the other buffers after its
 // MFMAs (one barrier per stage).  With COUT = 256 the four 64-channel output tiles are looped inside
 // the workgroup: the activation image (both chunks) stays resident, only weights stream.
-template <int CIN, int COUT>
+template <int CIN, int COUT, int NW_ = 8>
 struct PipeCfg {
-    static constexpr int NW = 8, NTHR = 64 * NW;           // 8 waves: two per SIMD, each owns MR = 2 tile rows (== launch bounds)
-    static constexpr int NT = 64, NB = 4, MR = 16 / NW, IW = 18, NPIX = 324, NSLOT = 336;
+    // NW_ = 8: two waves per SIMD on a 16 x 16 tile, the workgroup owns its CU (135 KB of LDS).  NW_ = 4 (the "lean" form): one
+    // wave per SIMD on an 8 x 16 tile, 96 KB of LDS and <= 256 VGPRs, so that a second workgroup - of this launch, or an
+    // HBM-bound stage-1 / stage-2 workgroup of ANOTHER frame's stream (<= 61 KB, <= 256 VGPRs) - shares the CU
+    static constexpr int NW = NW_, NTHR = 64 * NW;          // each wave owns MR = 2 tile rows (== launch bounds)
+    static constexpr int NT = 64, NB = 4, MR = 2, TH = MR * NW, IW = 18, NPIX = (TH + 2) * IW, NSLOT = (NPIX + 15) / 16 * 16;
     static constexpr int NCHUNK = CIN / 32, NCOT = COUT / 64;
-    static constexpr int A_PLANE = 4 * NSLOT * 16, A_BUF = 2 * A_PLANE;       // 43008 (hi + lo planes of one 32-channel chunk)
+    static constexpr int A_PLANE = 4 * NSLOT * 16, A_BUF = 2 * A_PLANE;       // 43008 / 24576 (hi + lo planes of one 32-channel chunk)
     static constexpr int B_PLANE = 3 * 4 * 64 * 16, B_BUF = 2 * B_PLANE;      // 24576 (hi + lo, 3 k-steps x 64 channels)
-    static constexpr int LDS_BYTES = 2 * A_BUF + 2 * B_BUF;                   // 135168
-    static constexpr int A_PART = NPIX * 4 / 3;                               // 432 (slot, cig) items per stage
+    static constexpr int LDS_BYTES = 2 * A_BUF + 2 * B_BUF;                   // 135168 / 98304
+    static constexpr int A_PART = NPIX * 4 / 3;                               // 432 / 240 (slot, cig) items per stage
     static constexpr int A_ITEMS = ((A_PART / 4 + 15) / 16 * 64 + NTHR - 1) / NTHR;   // per thread and part (lanes in 16-slot x 4-plane groups)
     static constexpr int B_ITEMS = 2 * 768 / NTHR;                            // uint4 per thread and stage
+    static_assert(NPIX % 3 == 0, "three equal parts");
 };
 
 // Pipeline: a stage = (32-channel chunk, tap row dy) = 3 k-steps.  Two activation buffers and two weight
@@ -785,9 +822,9 @@ struct PipeCfg {
 // buffers of stage s+1; one barrier per stage.  Fragments are double-buffered in registers across k-steps.
 // With COUT = 256 the four 64-channel output slices are looped inside the workgroup: the activation image
 // (both chunks) stays resident, only weights stream.
-template <int CIN, int COUT, bool IN_STATE, bool OUT_STATE>
-__global__ __launch_bounds__(512) void conv_pipe_kernel(const ConvArgs a) {
-    using C = PipeCfg<CIN, COUT>;
+template <int CIN, int COUT, bool IN_STATE, bool OUT_STATE, int NW = 8>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_pipe_kernel(const ConvArgs a) {
+    using C = PipeCfg<CIN, COUT, NW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const Abuf = smem;
     unsigned char* const Bbuf = smem + 2 * C::A_BUF;
@@ -796,7 +833,8 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const ConvArgs a) {
     const int lrow = lane & 15, kg = lane >> 4;
     int bx, by, b;
     if (!xcd_tile(a, bx, by, b)) return;
-    const int tx0 = bx * 16, ty0 = by * 16;
+    VST_TRACE_BEGIN(4)
+    const int tx0 = bx * 16, ty0 = by * C::TH;
     const float* const in_img = a.in + (size_t)b * a.in_img_stride;
     float* const out_img = a.out + (size_t)b * a.out_img_stride;
     const PackedConvLayout PL = packed_conv_layout(COUT, CIN);
@@ -823,18 +861,21 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const ConvArgs a) {
             a_src[part][it] = (unsigned)(off + cig * 8);
             a_dst[part][it] = (cig * C::NSLOT + slot) * 16;
         }
-    struct APart { float4 v[C::A_ITEMS][2]; };
-    struct BStage { uint4 v[C::B_ITEMS]; };
+    // (native vector arrays filled by macros, every index a compile-time constant after unrolling: as structs returned from
+    // lambdas the six-item stage of the 4-wave form was demoted to scratch)
+    typedef f32x4 APart[C::A_ITEMS][2];
+    typedef u32x4 BStage[C::B_ITEMS];
 #define LOAD_A(r, chunk, part)                                                          \
     _Pragma("unroll") for (int it_ = 0; it_ < C::A_ITEMS; ++it_) {                      \
         const float* p_ = in_img + a_src[part][it_] + (chunk) * 32;                     \
-        r.v[it_][0] = *(const float4*)p_; r.v[it_][1] = *(const float4*)(p_ + 4);       \
+        r[it_][0] = *(const f32x4*)p_; r[it_][1] = *(const f32x4*)(p_ + 4);             \
     }
+#define F4_(v_) make_float4((v_)[0], (v_)[1], (v_)[2], (v_)[3])
 #define STORE_A(buf, part, r)                                                           \
     _Pragma("unroll") for (int it_ = 0; it_ < C::A_ITEMS; ++it_) {                      \
         unsigned char* base_ = Abuf + (buf) * C::A_BUF;                                 \
         uint4 h_, l_;                                                                   \
-        split8(r.v[it_][0], r.v[it_][1], h_, l_);                                       \
+        split8(F4_(r[it_][0]), F4_(r[it_][1]), h_, l_);                                 \
         *(uint4*)(base_ + a_dst[part][it_]) = h_;                                       \
         *(uint4*)(base_ + C::A_PLANE + a_dst[part][it_]) = l_;                          \
     }
@@ -842,24 +883,26 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const ConvArgs a) {
     int b_off[C::B_ITEMS], b_dst[C::B_ITEMS];
 #pragma unroll
     for (int it = 0; it < C::B_ITEMS; ++it) {
-        const int idx = it * C::NTHR + tid;
-        const int plane = idx >= 768, r = idx - plane * 768;
-        const int k3 = r >> 8, kgi = (r >> 6) & 3, co = r & 63;
-        b_off[it] = (int)(plane * PL.frag_bytes) + ((k3 * 4 + kgi) * COUT + co) * 16;
-        b_dst[it] = plane * C::B_PLANE + r * 16;
+        if constexpr (NW == 4) {      // item it = (plane it / 3, k-step it % 3, thread = (kgi, co)): one base + constants
+            const int plane = it / 3, k3 = it % 3, kgi = tid >> 6, co = tid & 63;
+            b_off[it] = ((kgi * COUT + co) * 16) + (int)(plane * PL.frag_bytes) + k3 * 4 * COUT * 16;
+            b_dst[it] = tid * 16 + plane * C::B_PLANE + k3 * 256 * 16;
+        } else {
+            const int idx = it * C::NTHR + tid;
+            const int plane = idx >= 768, r = idx - plane * 768;
+            const int k3 = r >> 8, kgi = (r >> 6) & 3, co = r & 63;
+            b_off[it] = (int)(plane * PL.frag_bytes) + ((k3 * 4 + kgi) * COUT + co) * 16;
+            b_dst[it] = plane * C::B_PLANE + r * 16;
+        }
     }
-    auto load_b = [&](int q, int dy) -> BStage {
-        const int cot = q / C::NCHUNK, chunk = q - cot * C::NCHUNK;
-        const unsigned char* src = w_plane0 + ((size_t)(chunk * 9 + dy * 3) * 4 * COUT + cot * 64) * 16;
-        BStage r;
-#pragma unroll
-        for (int it = 0; it < C::B_ITEMS; ++it) r.v[it] = *(const uint4*)(src + b_off[it]);
-        return r;
-    };
-    auto store_b = [&](int buf, const BStage& r) {
-#pragma unroll
-        for (int it = 0; it < C::B_ITEMS; ++it) *(uint4*)(Bbuf + buf * C::B_BUF + b_dst[it]) = r.v[it];
-    };
+#define LOAD_B(r, q_, dy_)                                                              \
+    {                                                                                   \
+        const int cot_ = (q_) / C::NCHUNK, chunk_ = (q_) - cot_ * C::NCHUNK;            \
+        const unsigned char* src_ = w_plane0 + ((size_t)(chunk_ * 9 + (dy_) * 3) * 4 * COUT + cot_ * 64) * 16;   \
+        _Pragma("unroll") for (int it_ = 0; it_ < C::B_ITEMS; ++it_) r[it_] = *(const u32x4*)(src_ + b_off[it_]); \
+    }
+#define STORE_B(buf, r)                                                                 \
+    { _Pragma("unroll") for (int it_ = 0; it_ < C::B_ITEMS; ++it_) *(u32x4*)(Bbuf + (buf) * C::B_BUF + b_dst[it_]) = r[it_]; }
     struct Frags { bf16x8 wh[4], wl[4], xh[C::MR], xl[C::MR]; };
     auto read_frags = [&](Frags& f, const unsigned char* Ab, const unsigned char* Bb, int k3) {
 #pragma unroll
@@ -879,16 +922,21 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const ConvArgs a) {
     // ---- prologue: chunk 0 activations + stage 0 weights land in LDS; stage 1 weights and the first third of
     //      chunk 1 stay in registers (they are written to LDS during stage 0).  Register set[s&1] is loaded during
     //      stage s and stored during stage s+1.
-    BStage rb[2];
-    APart ra[2];
+    // (the 4-wave form stages twice as much per thread: it keeps ONE register set - a stage lands what the previous stage
+    // loaded and then reuses the registers for its own loads; the 8-wave form issues its loads first, into a second set)
+    constexpr bool ONE_SET = NW == 4;
+#define RS(i_) (ONE_SET ? 0 : (i_))
+    BStage rb[ONE_SET ? 1 : 2];
+    APart ra[ONE_SET ? 1 : 2];
     {
-        const BStage rb0 = load_b(0, 0);
+        BStage rb0;
+        LOAD_B(rb0, 0, 0);
         APart r0, r1, r2;
         LOAD_A(r0, 0, 0); LOAD_A(r1, 0, 1); LOAD_A(r2, 0, 2);
-        rb[1] = load_b(0, 1);
-        if (C::NCHUNK > 1) LOAD_A(ra[1], 1, 0);
+        LOAD_B(rb[RS(1)], 0, 1);
+        if (C::NCHUNK > 1) LOAD_A(ra[RS(1)], 1, 0);
         STORE_A(0, 0, r0); STORE_A(0, 1, r1); STORE_A(0, 2, r2);
-        store_b(0, rb0);
+        STORE_B(0, rb0);
     }
     __syncthreads();
 
@@ -900,7 +948,7 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const ConvArgs a) {
     const int slot_base = (wave * C::MR) * C::IW + lrow;
     const int oy0 = ty0 + wave * C::MR;
     float4 bias[4], old[C::MR][4];
-    const bool full_tile = ty0 + 16 <= a.Hout && tx0 + 16 <= a.Wout;    // uniform: interior tiles skip all predicates
+    const bool full_tile = ty0 + C::TH <= a.Hout && tx0 + 16 <= a.Wout; // uniform: interior tiles skip all predicates
     // Kernels that loop several 64-channel output slices (the 64 -> 256 conv: four) DEFER a slice's stores: at the slice's end
     // the results are formed in place in `old` (old + sign * (acc + bias)), and the eight float4 stores per lane go out one per
     // k-step during the next slice's first chunk, between its MFMAs - all eight waves used to issue them together behind the
@@ -921,13 +969,20 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const ConvArgs a) {
         for (int dy = 0; dy < 3; ++dy) {
             const int s = q * 3 + dy;
             const int cur = (qq * 3 + dy) & 1;            // compile-time parity of s
+            // ---- land what was loaded one stage ago in the buffers of stage s+1 (free since the last barrier) -------
+#define PIPE_LAND()                                                                                 \
+            if (!(VST_ABLATE & 2)) {                                                                \
+                if (s + 1 < 3 * Q) STORE_B((s + 1) & 1, rb[RS(cur ^ 1)]);                            \
+                if (q < C::NCHUNK - 1) STORE_A((chunk + 1) & 1, dy, ra[RS(cur ^ 1)]);                \
+            }
+            if constexpr (ONE_SET) { PIPE_LAND(); }
             // ---- issue the loads that are two stages ahead (consumed from registers during the NEXT stage) ----
             if (!(VST_ABLATE & 2)) {   // weights of stage s+2
                 const int q2 = dy == 0 ? q : q + 1, dy2 = (dy + 2) % 3;
-                if (q2 < Q) rb[cur] = load_b(q2, dy2);
+                if (q2 < Q) LOAD_B(rb[RS(cur)], q2, dy2);
                 // activations stored during stage s+1 = (qn, dyn): part dyn of chunk(qn)+1 (first output slice only)
                 const int qn = dy == 2 ? q + 1 : q, dyn = (dy + 1) % 3;
-                if (qn < C::NCHUNK - 1) LOAD_A(ra[cur], qn + 1, dyn);
+                if (qn < C::NCHUNK - 1) LOAD_A(ra[RS(cur)], qn + 1, dyn);
             }
             // (bias: a few cached bytes.  The multi-slice kernels fetch it at the slice's LAST stage top - live for one stage
             // instead of six - which pays for the longer-lived old values below)
@@ -944,11 +999,8 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const ConvArgs a) {
                 else load_old<COUT, C::MR, 4, false>(a, out_img, oy0, tx0 + lrow, cot * 64 + 4 * kg, old);
             }
 
-            // ---- land what was loaded one stage ago in the buffers of stage s+1 (free since the last barrier) -------
-            if (!(VST_ABLATE & 2)) {
-            if (s + 1 < 3 * Q) store_b((s + 1) & 1, rb[cur ^ 1]);
-            if (q < C::NCHUNK - 1) STORE_A((chunk + 1) & 1, dy, ra[cur ^ 1]);
-            }
+            if constexpr (!ONE_SET) { PIPE_LAND(); }
+#undef PIPE_LAND
 
             // ---- 3 k-steps of MFMAs on the current buffers; fragments are double-buffered in registers: the reads
             //      of k-step k+1 are issued before the MFMAs of k-step k --------------------------------------------
@@ -1018,6 +1070,11 @@ __global__ __launch_bounds__(512) void conv_pipe_kernel(const ConvArgs a) {
     }
 #undef LOAD_A
 #undef STORE_A
+#undef LOAD_B
+#undef STORE_B
+#undef F4_
+#undef RS
+    VST_TRACE_END_(4, CIN, COUT)
 }
 
 // Diagnostic fp32 direct convolution (VST_PREC_FP32): one thread per (pixel, co), plain FMA chain.
@@ -1077,6 +1134,13 @@ void vst_prof_close(int rec, hipStream_t st) {
     if (rec < g_prof_count) (void)hipEventRecord(g_prof_ev[2 * rec + 1], st);
 }
 
+// VST_OPT_STAGE3_LEAN (vstnet.h): the stage-3 convs of the bf16x3 mode as half-CU workgroups, see PipeCfg
+#ifndef VST_LEAN_DEFAULT
+#define VST_LEAN_DEFAULT 0
+#endif
+static std::atomic<int> g_opt_lean{[] { const char* e = getenv("VST_LEAN"); return e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : VST_LEAN_DEFAULT; }()};
+static bool vst_lean_stage3() { return g_opt_lean.load(std::memory_order_relaxed) != 0; }
+
 template <int CIN, int COUT, int STRIDE, bool IN_STATE, bool OUT_STATE>
 static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st, bool out_h16 = false) {
     if (precision == VST_PREC_FP32) {
@@ -1090,13 +1154,25 @@ static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st, 
     if (precision != VST_PREC_BF16X3 && !vst_is_f16(precision)) return VST_E_MODE;
     vst_prof_scope prof(VST_KERNEL_ID(CIN, COUT, STRIDE), st);
     if constexpr (CIN >= 64 && COUT >= 64 && STRIDE == 1) {
-        using C = PipeCfg<CIN, COUT>;
-        auto kern = conv_pipe_kernel<CIN, COUT, IN_STATE, OUT_STATE>;
-        static std::atomic<unsigned> attr_done{0};
-        if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)(C::LDS_BYTES), &attr_done)) return rc_;
         ConvArgs t = a;
-        t.tiles_x = (a.Wout + 15) / 16; t.tiles_y = (a.Hout + 15) / 16; t.tiles_total = t.tiles_x * t.tiles_y * B;
-        kern<<<dim3((t.tiles_total + 7) / 8 * 8), C::NTHR, C::LDS_BYTES, st>>>(t);
+        t.tiles_x = (a.Wout + 15) / 16;
+        if (vst_lean_stage3()) {                 // half-CU workgroups: see PipeCfg
+            using C = PipeCfg<CIN, COUT, 4>;
+            auto kern = conv_pipe_kernel<CIN, COUT, IN_STATE, OUT_STATE, 4>;
+            static std::atomic<unsigned> attr_done{0};
+            if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)(C::LDS_BYTES), &attr_done)) return rc_;
+            t.tiles_y = (a.Hout + C::TH - 1) / C::TH; t.tiles_total = t.tiles_x * t.tiles_y * B;
+            VST_TRACE_RESERVE(t, (t.tiles_total + 7) / 8 * 8)
+            kern<<<dim3((t.tiles_total + 7) / 8 * 8), C::NTHR, C::LDS_BYTES, st>>>(t);
+        } else {
+            using C = PipeCfg<CIN, COUT>;
+            auto kern = conv_pipe_kernel<CIN, COUT, IN_STATE, OUT_STATE>;
+            static std::atomic<unsigned> attr_done{0};
+            if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, (int)(C::LDS_BYTES), &attr_done)) return rc_;
+            t.tiles_y = (a.Hout + C::TH - 1) / C::TH; t.tiles_total = t.tiles_x * t.tiles_y * B;
+            VST_TRACE_RESERVE(t, (t.tiles_total + 7) / 8 * 8)
+            kern<<<dim3((t.tiles_total + 7) / 8 * 8), C::NTHR, C::LDS_BYTES, st>>>(t);
+        }
     } else {
         using C = ConvCfg<CIN, COUT, STRIDE>;
         // f16x2: the convs of the 16- and 64-channel blocks run the 2-term fp16 product as well (one weight plane in LDS: one
@@ -1114,6 +1190,7 @@ static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st, 
         ConvArgs t = a;
         t.tiles_x = (a.Wout + C::TW - 1) / C::TW; t.tiles_y = (a.Hout + C::TH - 1) / C::TH;
         t.tiles_total = t.tiles_x * t.tiles_y * B * C::NCOT;
+        VST_TRACE_RESERVE(t, (t.tiles_total + 7) / 8 * 8)
         kern<<<dim3((t.tiles_total + 7) / 8 * 8), 256, lds, st>>>(t);
     }
     VST_RETURN_IF_LAUNCH_FAILED();
@@ -1130,6 +1207,7 @@ static int launch_conv_s2_planes(const ConvArgs& a, int B, hipStream_t st) {
     ConvArgs t = a;
     t.tiles_x = (a.Wout + C::TW - 1) / C::TW; t.tiles_y = (a.Hout + C::TH - 1) / C::TH;
     t.tiles_total = t.tiles_x * t.tiles_y * B * C::NCOT;
+    VST_TRACE_RESERVE(t, (t.tiles_total + 7) / 8 * 8)
     kern<<<dim3((t.tiles_total + 7) / 8 * 8), 256, C::LDS_BYTES_T2, st>>>(t);
     VST_RETURN_IF_LAUNCH_FAILED();
     return VST_OK;
@@ -1156,6 +1234,7 @@ static int launch_pair(const ConvArgs& a, int B, int precision, hipStream_t st) 
         if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, P::LDS_BYTES, &attr_h16)) return rc_;
         ConvArgs t = a;
         t.tiles_x = (a.Wout + 15) / 16; t.tiles_y = (a.Hout + 15) / 16; t.tiles_total = t.tiles_x * t.tiles_y * B;
+        VST_TRACE_RESERVE(t, (t.tiles_total + 7) / 8 * 8)
         kern<<<dim3((t.tiles_total + 7) / 8 * 8), 256, P::LDS_BYTES, st>>>(t);
         VST_RETURN_IF_LAUNCH_FAILED();
         return VST_OK;
@@ -1172,6 +1251,7 @@ static int launch_pair(const ConvArgs& a, int B, int precision, hipStream_t st) 
     if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, lds, &attr_done[t2 ? 1 : 0])) return rc_;
     ConvArgs t = a;
     t.tiles_x = (a.Wout + 15) / 16; t.tiles_y = (a.Hout + th - 1) / th; t.tiles_total = t.tiles_x * t.tiles_y * B;
+    VST_TRACE_RESERVE(t, (t.tiles_total + 7) / 8 * 8)
     kern<<<dim3((t.tiles_total + 7) / 8 * 8), 256, lds, st>>>(t);
     VST_RETURN_IF_LAUNCH_FAILED();
     return VST_OK;
@@ -1247,6 +1327,17 @@ static const int kBlockStride[VST_NUM_BLOCKS] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2
 VST_DEFINE_TU_RANGE(vst_range_tu_conv)
 
 extern "C" {
+
+int vst_set_option(int option, int value) {
+    if (option != VST_OPT_STAGE3_LEAN) return VST_E_ARG;
+    g_opt_lean.store(value != 0, std::memory_order_relaxed);
+    return VST_OK;
+}
+
+int vst_get_option(int option) {
+    if (option != VST_OPT_STAGE3_LEAN) return VST_E_ARG;
+    return g_opt_lean.load(std::memory_order_relaxed);
+}
 
 int vst_range_flags(unsigned* flags_host, int reset) {
     if (!flags_host) return VST_E_ARG;
