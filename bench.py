@@ -28,7 +28,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_16BIT_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak
-PMC_FILE = "r03_pmc_hbm_traffic.json"   # committed rocprofv3 --pmc summary that `roofline.traffic` is read from (never measured live)
+PMC_FILE = "r04_pmc_hbm_traffic.json"   # committed rocprofv3 --pmc summary that `roofline.traffic` is read from (never measured live)
 
 # conv kernel classes by profile id (cin, cout, stride) -> (stage, output-pixel divisor w.r.t. the full-resolution frame,
 # multiply-accumulates per output pixel and launch); the (4,16) and (16,64) ids are the fused conv.4 + conv.7 launches
@@ -72,6 +72,8 @@ def parse_args(argv=None):
                     "reported as an extra field, never as `value`)")
     ap.add_argument("--streams", type=int, default=3, help="independent frames in flight per GPU, one HIP stream each "
                     "(the MFMA-bound and the HBM-bound kernels of different frames overlap); 1 = strictly sequential")
+    ap.add_argument("--stage3-lean", type=int, default=None, choices=[0, 1], help="VST_OPT_STAGE3_LEAN (vstnet.h): the bf16x3 256-channel "
+                    "convs as half-CU workgroups (measured: slower, profiles/r04_lean_overlap.json; default: the library's, 0)")
     ap.add_argument("--dry-run-ms", type=float, default=0.0, help="host-logic rehearsal (tests): no GPU work, a step sleeps "
                     "this many milliseconds; exercises launch, rendezvous, timing and the JSON line only")
     return ap.parse_args(argv)
@@ -109,6 +111,8 @@ def main():
     from vstnet_amd import _lib
     from vstnet_amd.synth import synthetic_state_dict, synthetic_frames
     args.precision = args.precision or _lib.default_precision()
+    if args.stage3_lean is not None:
+        _lib.set_option(_lib.OPT_STAGE3_LEAN, args.stage3_lean)
     n_dev = torch.cuda.device_count()          # counting devices does not initialise HIP
     use_nccl = world <= n_dev                 # fewer GPUs than ranks (rehearsal on a 1-GPU box): ranks share GPUs, gloo
     if world > 1:
@@ -294,6 +298,7 @@ def main():
                    f"forward + cWCT ({str(args.masked) + '-label ' + args.mask_kind + ' masks, ' if args.masked else ''}{'style re-encoded per frame' if args.recompute_style else 'style statistics cached'})"
                    " + RevResNet inverse", "frames_per_gpu": fpg, "sharding": f"{world} ranks x {fpg} frame(s), no collective",
                    "weights": "synthetic seed 1234", "frames_in_flight": max(1, args.streams), "precision": args.precision,
+                   "stage3_lean": _lib.get_option(_lib.OPT_STAGE3_LEAN),
                    "resolved_precision": net.resolved_precision},
         "per_rank": {"frames_per_s": per_rank_fps, "min": min(per_rank_fps), "max": max(per_rank_fps)},
         "frame_hbm_roofline": {"bound": "hbm", "algorithmic_bytes_per_frame": frame_bytes,
@@ -301,7 +306,8 @@ def main():
                                "frac": round(frame_gbs / HBM_PEAK_GBS, 4), "per": "GPU"},
     }
     if rank == 0 and table:
-        rec["roofline"], rec["stages"] = roofline_from_table(table, n_prof, fpg, Hf, Wf, args, _lib)
+        rec["roofline"], rec["stages"], rec["kernel_classes"], rec["frame_level"] = roofline_from_table(
+            table, n_prof, fpg, Hf, Wf, args, _lib, ms_per_step=ms_per_step / fpg, frames_in_flight=max(1, args.streams))
     rec.update(extras)
     if rank == 0:
         rec["fp16_range_flags"] = {"value": int(range_flags), "note": "device-side flags since process start (vstnet.h VST_RANGE_*: "
@@ -354,9 +360,38 @@ def conv_terms(f16, cin, cout, stride):
     return 2 if f16 else 3
 
 
-def roofline_from_table(table, n_frames, fpg, H, W, args, _lib):
-    """Per-launch roofline of the conv class with the largest total time, and a per-stage summary, from the HIP-event
-    table of `n_frames` frames run one at a time (ms are per frame below)."""
+def kernel_label(cin, cout, stride, terms):
+    if cin >= 64 and cout >= 64 and stride == 1:
+        return (f"conv_sp_kernel<{cin},{cout}> (fp16 {terms}-term, LDS-DMA)" if terms <= 2
+                else f"conv_pipe_kernel<{cin},{cout}> (bf16 3-term)")
+    fused = (cin, cout) in ((4, 16), (16, 64))
+    return (f"{'conv_pair_kernel' if fused else 'conv_mfma_kernel'}<{cin},{cout}{',s2' if stride == 2 else ''}> "
+            f"({'fp16 2-term' if terms == 2 else 'bf16 3-term'}{', conv.4 + conv.7 fused' if fused else ''})")
+
+
+# profile-table ids of the non-conv launches -> the kernels of the PMC summary that make up such a launch
+MISC_PMC = {1: ("pack_input_kernel", "block0_const_kernel"), 2: ("unpack_output_kernel",), 3: ("spread_gather_kernel",),
+            4: ("spread_gather_kernel",), 5: ("cwct_stats_pm_kernel", "cwct_stats_finish_kernel"), 6: ("cwct_factor_kernel",),
+            7: ("cwct_apply_pm_kernel",), 8: ("presplit_kernel",)}
+
+
+def pmc_lookup(pmc, cin, cout, stride):
+    """HBM bytes per launch of a conv class from the committed PMC summary (None if the class is not in it)"""
+    if cin >= 64 and cout >= 64 and stride == 1:
+        pats = [f"conv_pipe_kernel<{cin}, {cout},", f"conv_sp_kernel<{cin}, {cout},"]
+    elif (cin, cout) in ((4, 16), (16, 64)) and stride == 1:
+        pats = [f"conv_pair_kernel<{cin}, {cout},"]
+    else:
+        pats = [f"conv_mfma_kernel<{cin}, {cout}, {stride},"]
+    hit = [v for n, v in pmc["kernels"].items() if any(t in n for t in pats)]
+    return hit[0]["hbm_bytes_per_launch"] if hit else None
+
+
+def roofline_from_table(table, n_frames, fpg, H, W, args, _lib, ms_per_step=None, frames_in_flight=1):
+    """From the HIP-event table of `n_frames` frames run one at a time (ms are per frame below): the per-launch roofline of the
+    conv class with the largest total time (BOTH roofs; the binding one is decided on the ISSUED matrix work: terms x flops),
+    the five classes with the largest totals, a per-stage summary, and the frame-level picture (HBM bytes per frame by the
+    committed PMC summary, chip-average TB/s and issued PFLOP/s at the timed region's ms per step)."""
     px = fpg * H * W                                   # full-resolution pixels per frame batch
     prec = getattr(args, "effective_precision", None) or args.precision
     f16 = "h" if prec == "f16x2h" else prec == "f16x2"      # truthy for both fp16 modes
@@ -364,67 +399,92 @@ def roofline_from_table(table, n_frames, fpg, H, W, args, _lib):
     for kid, (ms, cnt) in table.items():
         if kid >= 65536:
             per[(kid >> 16, (kid >> 4) & 0xFFF, kid & 15)] = (ms / n_frames, cnt / n_frames)
-    # ---- dominant conv class -------------------------------------------------------------------------------------------
     per = {k: v for k, v in per.items() if k in CONV_CLASSES}
-    (cin, cout, stride), (ms, cnt) = max(per.items(), key=lambda kv: kv[1][0])
-    _, div, macs = CONV_CLASSES[(cin, cout, stride)]
-    flops = 2.0 * 9 * macs * px / div                  # fp32-equivalent conv flops of one launch
-    avg_ms = ms / cnt
-    terms = conv_terms(f16, cin, cout, stride)
-    achieved = flops / (avg_ms * 1e-3) / 1e12
-    if terms <= 2 and cin >= 64 and cout >= 64 and stride == 1:
-        kname = f"conv_sp_kernel<{cin},{cout}> (fp16 {terms}-term, LDS-DMA)"
-    else:
-        kname = f"conv kernel <{cin},{cout},s{stride}> ({'fp16 2-term' if terms == 2 else 'bf16 3-term'})"
     # `traffic` is NOT measured in this run: rocprofv3 PMC counters need their own passes (separate --pmc runs); it is read from
     # the committed summary of such a run of this same command, and `traffic_source` says which file, for which precision, from
     # which commit — a kernel edited since then makes it stale, which the commit hash shows.
-    traffic, traffic_source = None, None
+    pmc, traffic_source = None, None
     pmc_path = os.path.join(REPO, "profiles", PMC_FILE)
     if os.path.exists(pmc_path) and (H, W) == (1024, 1024) and fpg == 1 and args.mode == "photo":
-        pmc = json.load(open(pmc_path))
-        if pmc.get("precision", "f16x2h") == prec:
-            names = [f"<{cin}, {cout},", f"<{cin},{cout},"]
-            hit = [v for n, v in pmc["kernels"].items() if any(t in n for t in names) and ("conv_sp" in n or "conv_pipe" in n or "conv_mfma" in n)]
-            traffic = hit[0]["hbm_bytes_per_launch"] if hit else None
+        cand = json.load(open(pmc_path))
+        if cand.get("precision", "f16x2h") == prec:
+            pmc = cand
             traffic_source = {"file": "profiles/" + PMC_FILE, "precision": pmc.get("precision", "f16x2h"),
                               "git_commit": pmc.get("git_commit"), "collected": "rocprofv3 --pmc, separate passes (not this run)"}
-    # Both roofs of the launch; the binding one (the larger minimum time) is reported as `bound` / `achieved` / `frac`.
-    per_px = CONV_BYTES[(cin, cout, stride)]
-    if f16 == "h":                                         # fp16 tensors where f16x2 moves hi + lo pairs (or fp32)
-        per_px -= {(256, 64, 1): 512 + 128, (64, 64, 1): 128 + 128, (64, 256, 1): 128,      # state hi plane, h1, h2 of the 256-channel blocks
-                   (16, 4, 1): 8, (4, 16, 1): 8, (64, 16, 1): 32, (16, 64, 1): 32, (16, 16, 2): 32}.get((cin, cout, stride), 0)
-    nbytes = per_px * px / div
-    tbps = nbytes / (avg_ms * 1e-3) / 1e12
-    t_hbm, t_mfma = nbytes / (HBM_PEAK_GBS * 1e9), flops / (MFMA_16BIT_PEAK_TFLOPS * 1e12)
-    both = {"hbm": {"algorithmic_bytes": int(nbytes), "achieved_GBps": round(tbps * 1e3, 1), "frac": round(tbps * 1e3 / HBM_PEAK_GBS, 4)},
-            "mfma": {"algorithmic_flops": int(flops), "achieved_TFLOPps": round(achieved, 2),
-                     "frac": round(achieved / MFMA_16BIT_PEAK_TFLOPS, 4), "issued_frac": round(achieved * terms / MFMA_16BIT_PEAK_TFLOPS, 4)}}
-    roof = {"kernel": kname + " — the conv class with the largest total time per frame",
-            "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": round(avg_ms, 5), "launches_per_frame": round(cnt, 1), "ms_per_frame": round(ms, 4),
-            "both_roofs": both,
-            "note": "the roof with the larger minimum time for the launch's ALGORITHMIC bytes / fp32 conv flops (2*9*cin*cout per output "
-                    f"pixel) binds; the split issues {terms}x the algorithmic flops on the MFMA pipe (issued_frac); HIP events on the "
-                    "launch stream, one frame at a time"}
-    if t_hbm >= t_mfma:
-        roof.update({"bound": "hbm", "achieved": round(tbps * 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(tbps * 1e3 / HBM_PEAK_GBS, 4)})
+
+    def klass(key):
+        """both roofs of one conv class"""
+        cin, cout, stride = key
+        ms, cnt = per[key]
+        _, div, macs = CONV_CLASSES[key]
+        terms = conv_terms(f16, cin, cout, stride)
+        flops = 2.0 * 9 * macs * px / div              # fp32-equivalent conv flops of one launch
+        avg_ms = ms / cnt
+        per_px = CONV_BYTES[key]
+        if f16 == "h":                                     # fp16 tensors where f16x2 moves hi + lo pairs (or fp32)
+            per_px -= {(256, 64, 1): 512 + 128, (64, 64, 1): 128 + 128, (64, 256, 1): 128,  # state hi plane, h1, h2 of the 256-channel blocks
+                       (16, 4, 1): 8, (4, 16, 1): 8, (64, 16, 1): 32, (16, 64, 1): 32, (16, 16, 2): 32}.get(key, 0)
+        nbytes = per_px * px / div
+        traffic = pmc_lookup(pmc, cin, cout, stride) if pmc else None
+        t = avg_ms * 1e-3
+        t_hbm, t_mfma_issued = nbytes / (HBM_PEAK_GBS * 1e9), flops * terms / (MFMA_16BIT_PEAK_TFLOPS * 1e12)
+        rec = {"kernel": kernel_label(cin, cout, stride, terms), "launches_per_frame": round(cnt, 1), "avg_launch_us": round(avg_ms * 1e3, 2),
+               "ms_per_frame": round(ms, 4),
+               "hbm": {"algorithmic_bytes": int(nbytes), "algorithmic_GBps": round(nbytes / t / 1e9, 1),
+                       "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4), "pmc_bytes": traffic,
+                       "pmc_GBps": round(traffic / t / 1e9, 1) if traffic else None,
+                       "pmc_over_algorithmic": round(traffic / nbytes, 3) if traffic else None},
+               "mfma": {"algorithmic_flops": int(flops), "terms": terms, "algorithmic_TFLOPps": round(flops / t / 1e12, 2),
+                        "issued_TFLOPps": round(flops * terms / t / 1e12, 2),
+                        "frac": round(flops / t / 1e12 / MFMA_16BIT_PEAK_TFLOPS, 4),
+                        "issued_frac": round(flops * terms / t / 1e12 / MFMA_16BIT_PEAK_TFLOPS, 4)},
+               "min_us_at_peak": {"hbm": round(t_hbm * 1e6, 2), "mfma_issued": round(t_mfma_issued * 1e6, 2)},
+               "bound": "mfma" if t_mfma_issued > t_hbm else "hbm"}
+        return rec
+
+    classes = {k: klass(k) for k in per}
+    top = sorted(classes, key=lambda k: -per[k][0])
+    dom = classes[top[0]]
+    roof = {"kernel": dom["kernel"] + " — the conv class with the largest total time per frame",
+            "bound": dom["bound"], "traffic": dom["hbm"]["pmc_bytes"], "traffic_source": traffic_source,
+            "avg_launch_ms": round(dom["avg_launch_us"] * 1e-3, 5), "launches_per_frame": dom["launches_per_frame"],
+            "ms_per_frame": dom["ms_per_frame"],
+            "both_roofs": {"hbm": dom["hbm"], "mfma": dom["mfma"], "min_us_at_peak": dom["min_us_at_peak"]},
+            "note": "the binding roof is the one with the larger minimum time for the launch: ALGORITHMIC bytes at the HBM peak against the "
+                    f"ISSUED matrix work ({dom['mfma']['terms']} MFMA terms per product x 2*9*cin*cout flops per output pixel) at the dense "
+                    "16-bit MFMA peak; HIP events on the launch stream, one frame at a time"}
+    if dom["bound"] == "hbm":
+        roof.update({"achieved": dom["hbm"]["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["hbm"]["frac"],
+                     "mfma_issued_frac": dom["mfma"]["issued_frac"]})
     else:
-        roof.update({"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_16BIT_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / MFMA_16BIT_PEAK_TFLOPS, 4)})
+        roof.update({"achieved": dom["mfma"]["issued_TFLOPps"], "peak": MFMA_16BIT_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": dom["mfma"]["issued_frac"], "achieved_is": "issued MFMA flops (terms x algorithmic) per second",
+                     "algorithmic_frac": dom["mfma"]["frac"], "hbm_frac": dom["hbm"]["frac"]})
     # ---- per-stage summary ------------------------------------------------------------------------------------------------
     stage_ms = {"stage1": 0.0, "stage2": 0.0, "stage3": 0.0, "cwct": 0.0, "glue": 0.0}
     stage_issued = {"stage1": 0.0, "stage2": 0.0, "stage3": 0.0}
+    stage_pmc = {"stage1": 0.0, "stage2": 0.0, "stage3": 0.0, "cwct": 0.0, "glue": 0.0}
+    pmc_complete = pmc is not None
     for (ci, co, st_), (m, c) in per.items():
         stg, dv, mc = CONV_CLASSES[(ci, co, st_)]
         stage_ms[stg] += m
         t = conv_terms(f16, ci, co, st_)
         stage_issued[stg] += 2.0 * 9 * mc * px / dv * c * t
+        tb = classes[(ci, co, st_)]["hbm"]["pmc_bytes"]
+        if tb is None:
+            pmc_complete = False
+        else:
+            stage_pmc[stg] += tb * c
     for kid, (m, c) in table.items():
         if kid < 65536:
             name = _lib.MISC_KERNELS.get(kid, "")
             key = "cwct" if name.startswith("cwct") else ("stage3" if name == "presplit" else "glue")
             stage_ms[key] += m / n_frames
+            if pmc:
+                for pat in MISC_PMC.get(kid, ()):
+                    hit = [v for n, v in pmc["kernels"].items() if n.split("(")[0].split("<")[0].replace("void ", "") == pat]
+                    if hit:
+                        stage_pmc[key] += hit[0]["hbm_bytes_per_launch"] * c / n_frames
     # algorithmic bytes per frame (SURVEY 8(d)): 192 B per full-res pixel and block, 396 B glue per pass, 384 B cWCT
     blocks = {"stage1": 10 + 10 - 1, "stage2": 20, "stage3": 24}          # forward block 0 is folded into the input packing
     stage_bytes = {k: v * 192.0 * px for k, v in blocks.items()}
@@ -436,11 +496,37 @@ def roofline_from_table(table, n_frames, fpg, H, W, args, _lib):
     stages = {}
     for k, m in stage_ms.items():
         stages[k] = {"ms_per_frame": round(m, 4), "algorithmic_TBps": round(stage_bytes[k] / (m * 1e-3) / 1e12, 3) if m > 0 else None}
+        if pmc_complete and m > 0:
+            stages[k]["pmc_bytes_per_frame"] = int(stage_pmc[k])
+            stages[k]["pmc_TBps"] = round(stage_pmc[k] / (m * 1e-3) / 1e12, 3)
         if k in stage_issued:
             stages[k]["issued_PFLOPps"] = round(stage_issued[k] / (m * 1e-3) / 1e15, 3) if m > 0 else None
     stages["sum_ms_per_frame"] = round(sum(stage_ms.values()), 4)
     stages["note"] = "HIP-event kernel time of one frame at a time (launch gaps included per launch); stage3 includes channel_reduction"
-    return roof, stages
+    # ---- the frame as a whole --------------------------------------------------------------------------------------------
+    passes = 3 if args.recompute_style else 2
+    alg_frame = (passes * 6540 + 384) * H * W * fpg + (128 * H * W if args.recompute_style else 0)
+    issued_frame = sum(stage_issued.values())
+    frame = {"algorithmic_bytes_per_frame": int(alg_frame), "issued_mfma_flops_per_frame": int(issued_frame),
+             "kernel_time_sum_ms": stages["sum_ms_per_frame"], "frames_in_flight": frames_in_flight}
+    if ms_per_step:
+        t = ms_per_step * 1e-3
+        frame.update({"ms_per_frame_timed_region": round(ms_per_step, 4),
+                      "overlap_of_kernel_time": round(1.0 - ms_per_step / stages["sum_ms_per_frame"], 4),
+                      "chip_average_issued_PFLOPps": round(issued_frame / t / 1e15, 3),
+                      "chip_average_issued_frac_of_mfma_peak": round(issued_frame / t / 1e12 / MFMA_16BIT_PEAK_TFLOPS, 4),
+                      "chip_average_algorithmic_TBps": round(alg_frame / t / 1e12, 3)})
+    if pmc_complete and not args.recompute_style:
+        pmc_frame = sum(stage_pmc.values())
+        frame.update({"pmc_bytes_per_frame": int(pmc_frame), "pmc_over_algorithmic": round(pmc_frame / alg_frame, 3),
+                      "pmc_source": traffic_source})
+        if ms_per_step:
+            frame["chip_average_pmc_TBps"] = round(pmc_frame / (ms_per_step * 1e-3) / 1e12, 3)
+            frame["chip_average_pmc_frac_of_hbm_peak"] = round(pmc_frame / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    frame["note"] = ("pmc_bytes_per_frame = sum over this run's launches per frame (HIP-event table) x HBM bytes per launch of the committed "
+                     "PMC summary; chip averages divide by the timed region's ms per frame (frames in flight on several streams); "
+                     "overlap_of_kernel_time = 1 - ms per frame / sum of kernel times of a frame run alone")
+    return roof, stages, [classes[k] for k in top[:5]], frame
 
 
 def dry_run(args, rank, world):

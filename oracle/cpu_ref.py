@@ -161,7 +161,8 @@ def cholesky_dec(conv, eps=2e-5, invert=False, return_tries=False):
     tries = 0
     L, info = torch.linalg.cholesky_ex(conv)
     if int(info.max()) != 0:
-        iden = torch.eye(conv.shape[-1], dtype=conv.dtype)
+        iden = torch.eye(conv.shape[-1])        # float32 like the reference's (models/cWCT.py:120), also under use_double:
+                                                # the float64 covariance then receives eps rounded to float32
         e = eps
         while True:
             conv = conv + iden * e

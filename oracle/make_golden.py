@@ -163,7 +163,10 @@ def main():
     for tag, arch, hw in (("A", dict(nBlocks=[2, 3, 2], nStrides=[1, 2, 2], nChannels=[4, 16, 64], in_channel=3, mult=2,
                                      hidden_dim=4, sp_steps=2, kernel=3), (16, 24)),
                           ("B", dict(nBlocks=[1, 2], nStrides=[1, 2], nChannels=[4, 16], in_channel=1, mult=4, hidden_dim=16,
-                                     sp_steps=1, kernel=5), (12, 20))):
+                                     sp_steps=1, kernel=5), (12, 20)),
+                          # C: a mult that does not divide the channels - the reference floors (channel // mult, :81): 2 and 10
+                          ("C", dict(nBlocks=[1, 2], nStrides=[1, 2], nChannels=[8, 32], in_channel=3, mult=3, hidden_dim=8,
+                                     sp_steps=2, kernel=3), (16, 24))):
         with contextlib.redirect_stdout(io.StringIO()):
             gnet = ref_rev.RevResNet(**arch)
         gsd = {}
@@ -321,6 +324,22 @@ def main():
     om = cwd.transfer(cd.clone(), sd1.clone(), cmd, smd)
     check("use_double transfer_seg", cpu_ref.transfer_seg(cd, sd1, cmd, smd, use_double=True), om, 1e-6)
     gd.update(cmask=cmd, smask=smd, masked=om)
+    # the jitter branch under use_double (cWCT.py:115-128): a constant channel is an exactly zero pivot in any arithmetic -> one
+    # retry.  The identity the reference adds is float32 (torch.eye's default) although the covariance is float64, so the
+    # jitter is eps ROUNDED TO FLOAT32; an oracle adding the float64 eps is 1e-8 away, this check (1e-12) tells them apart.
+    cjd = rnd((1, N, 8, 8), 970)
+    cjd[0, N - 1] = 0.25
+    sjd = rnd((1, N, 6, 10), 971) * 0.7
+    oj = cwd.interpolation(cjd, [sjd], [1.0], 0.0)
+    assert oj.dtype == torch.float32 and bool(torch.isfinite(oj).all())
+    oj64 = cpu_ref.interpolation(cjd, [sjd], [1.0], 0.0, use_double=True)
+    check("use_double jitter branch (rank-deficient code)", oj64, oj, 1e-12)
+    cjc = cjd.reshape(1, N, -1).double()
+    cjc = cjc - cjc.mean(-1, keepdim=True)
+    _, tjd = cpu_ref.cholesky_dec(cjc @ cjc.transpose(-1, -2) / 63, return_tries=True)
+    print(f"  use_double jitter branch: retries = {tjd}, max|out| = {float(oj.abs().max()):.3g}")
+    assert tjd >= 1
+    gd.update(c_jit=cjd, s_jit=sjd, interp_jit=oj, jit_tries=tjd)
     save("cwct_double", **gd)
 
     # ------------------------------------------------------------------ mask producers (8(f) rank 3)

@@ -36,3 +36,18 @@ def test_world_size_mismatch_is_an_error():
 def test_failed_rank_fails_the_launch():
     p = _run(["--gpus", "2", "--steps", "0", "--dry-run-ms", "1"])     # 0 steps: every rank divides by zero
     assert p.returncode != 0
+
+
+def test_self_launch_eight_ranks():
+    """the driver's 8-GPU shape: eight self-launched ranks rendezvous on 127.0.0.1, the barrier + max-over-
+    ranks clock works, rank 0 prints ONE line whose per-rank report has eight entries"""
+    p = _run(["--gpus", "8", "--steps", "4", "--warmup", "1", "--dry-run-ms", "25", "--frames-per-gpu", "4"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["steps"] == 4 and rec["scaling"] == "weak"
+    assert len(rec["per_rank"]["frames_per_s"]) == 8
+    # 8 ranks x 4 frames per step, steps of >= 25 ms: the aggregate cannot exceed 32 frames per 25 ms
+    assert 0 < rec["value"] <= 32 / 0.025 * 1.001
+    assert rec["per_rank"]["max"] <= 4 / 0.025 * 1.001

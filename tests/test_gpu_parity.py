@@ -176,12 +176,13 @@ def test_network_vs_oracle_ragged(mode, shape, precision):
 def test_general_architectures_golden(golden):
     """RevResNet with the reference's OTHER constructor arguments (models/RevResNet.py:166-201) runs on the generic HIP ops
     (csrc/generic.hip: exact fp32): two nets against goldens minted from the reference — A: three short stages, mult 2; B: two
-    stages, 1-channel input, kernel 5, a channel_reduction that pads 16 -> 64 channels per half — plus an architecture one step
+    stages, 1-channel input, kernel 5, a channel_reduction that pads 16 -> 64 channels per half; C: mult = 3 on 8 / 32 channels
+    (2 and 10 intermediate channels: the reference floors) — plus an architecture one step
     off the published one against the oracle."""
     import ast
     from models.RevResNet import RevResNet
     g = golden("net_general")
-    for tag in ("A", "B"):
+    for tag in ("A", "B", "C"):       # (C: mult = 3 does not divide 8 or 32 channels; the reference floors, models/RevResNet.py:81)
         arch = ast.literal_eval(str(g[f"{tag}_arch"]))
         net = RevResNet(**arch)
         net.load_state_dict({k[len(tag) + 3:]: T(g[k]) for k in g.files if k.startswith(f"{tag}_w_")})
@@ -196,6 +197,8 @@ def test_general_architectures_golden(golden):
             net(x[:, :, :-1])                                        # not a multiple of down_scale
         with pytest.raises(NotImplementedError):
             net.forward_u8(torch.zeros(1, 8, 8, 3, dtype=torch.uint8, device="cuda"))
+    with pytest.raises(ValueError):
+        RevResNet(nBlocks=[1], nStrides=[1], nChannels=[4], mult=8, hidden_dim=4)
     # nBlocks = [2, 2, 2] of the published channel plan, with the cWCT in between, against the oracle
     from models.cWCT import cWCT
     arch = dict(nBlocks=[2, 2, 2], nStrides=[1, 2, 2], nChannels=[16, 64, 256], hidden_dim=16, sp_steps=2)
@@ -642,6 +645,10 @@ def test_cwct_use_double_golden(golden):
     out = cwd.transfer(c.clone(), s1, g["cmask"], g["smask"])
     assert_close(out, T(g["masked"]), 2e-6, "use_double transfer_seg")
     assert_close(cwd.transfer(c, s1), cpu_ref.transfer(T(g["c"]), T(g["s1"]), use_double=True), 2e-6, "use_double transfer")
+    # the fp64 jitter branch (csrc/cwct64.hip: same failure rule, eps rounded to float32 like the reference's float32 identity,
+    # models/cWCT.py:120-124) on a code with a constant channel: one retry, golden minted from the reference
+    cj, sj = T(g["c_jit"]).cuda(), T(g["s_jit"]).cuda()
+    assert_close(cwd.interpolation(cj, [sj], [1.0], 0.0), T(g["interp_jit"]), 2e-6, "use_double jitter branch")
     # packed codes are materialised, the 2-D helpers run in fp64 too
     net, sd, sp = make_net("photo")
     z, zs = net(synthetic_frames(1, 32, 48, seed=1).cuda()), net(synthetic_frames(1, 32, 48, seed=2).cuda())

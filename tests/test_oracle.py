@@ -181,6 +181,14 @@ def test_cwct_use_double(golden):
         d32 = (cpu_ref.interpolation(c, [s1, s2], [0.7, 0.3], ac) - T(g[f"interp_ac{ac}"])).abs().max()
         assert float(d32) > 1e-3
     close(cpu_ref.transfer_seg(c, s1, g["cmask"], g["smask"], use_double=True), T(g["masked"]), 1e-6)
+    # the jitter branch under use_double (a constant channel: an exactly zero pivot -> one retry); the reference adds a float32
+    # identity times eps to the float64 covariance (models/cWCT.py:120-124), and so does the oracle
+    cj, sj = T(g["c_jit"]), T(g["s_jit"])
+    out = cpu_ref.interpolation(cj, [sj], [1.0], 0.0, use_double=True)
+    close(out, T(g["interp_jit"]), 1e-6)
+    x = cj.reshape(1, 32, -1).double()
+    x = x - x.mean(-1, keepdim=True)
+    assert cpu_ref.cholesky_dec(x @ x.transpose(-1, -2) / 63, return_tries=True)[1] == int(g["jit_tries"]) == 1
 
 
 def _general_case(g, tag):
@@ -194,7 +202,7 @@ def test_general_architectures(golden):
     """the reference's other constructor arguments (models/RevResNet.py:166-201: nBlocks / nStrides / nChannels / in_channel / mult
     / hidden_dim / sp_steps / kernel), goldens minted from the reference for two such nets (weights inside the fixture)"""
     g = golden("net_general")
-    for tag in ("A", "B"):
+    for tag in ("A", "B", "C"):
         arch, sd = _general_case(g, tag)
         x = T(g[f"{tag}_x"])
         with torch.no_grad():

@@ -22,6 +22,7 @@ own ring buffers and mask plan instead of an error; the writer size comes from t
 import sys
 import argparse
 import os
+import re
 
 import numpy as np
 import torch
@@ -30,14 +31,14 @@ from PIL import Image
 
 from image_transfer import build_network
 from utils.utils import img_resize, load_segment, to_tensor_u8
-from vstnet_amd.pipeline import FramePipeline, AsyncSink, prefetch
+from vstnet_amd.pipeline import FramePipeline, AsyncSink, prefetch, parallel_map, host_workers, save_png
 from vstnet_amd.sharding import shard_range
 
 IMG_EXT = ('.jpg', '.jpeg', '.png', '.ppm', '.bmp')
 
 
 def build_parser():
-    p = argparse.ArgumentParser()
+    p = argparse.ArgumentParser(allow_abbrev=False)     # (an abbreviated --gpu would survive launch_shards' argv rewrite)
     p.add_argument('--mode', type=str, default='photorealistic')
     p.add_argument('--ckpoint', type=str, default='checkpoints/photo_video.pt')
     p.add_argument('--video', type=str, default='data/content/03.avi')
@@ -57,7 +58,13 @@ def build_parser():
                    "(what the children of --gpus N do: the parent encodes the one clip)")
     p.add_argument('--stub_stylise', action='store_true', default=False, help=argparse.SUPPRESS)   # host-logic tests: no GPU
     p.add_argument('--depth', type=int, default=4, help="pinned ring slots (frames queued ahead of the one being written)")
-    p.add_argument('--streams', type=int, default=2, help="frames in flight on the card")
+    p.add_argument('--streams', type=int, default=3, help="frames in flight on the card (1080p, 5-label masks, files in -> PNGs out: "
+                   "89 / 102 / 103 frames/s at 2 / 3 / 4, profiles/r04_other_configs.jsonl)")
+    p.add_argument('--workers', type=int, default=0, help="host threads that decode + resize input frames, and as many that "
+                   "encode output frames (0: a share of this process's cores); the GPU loop itself is one thread")
+    p.add_argument('--png_level', type=int, default=0, help="numbered PNGs (the output without cv2, and the shard -> parent "
+                   "hand-off of --gpus N): 0 = stored rows, a few ms per 1080p frame, 3 bytes per pixel; 1-9 = PIL's filters + "
+                   "zlib at that level (about 30 %% smaller on photographs, 10-30x the encode time).  Lossless either way")
     return p
 
 
@@ -104,18 +111,31 @@ def clip_name(args):
     return "%s_%s" % (os.path.basename(args.video.rstrip("/")).split(".")[0], os.path.basename(args.style).split(".")[0])
 
 
+FRAME_PNG = re.compile(r"^\d{5}\.png$")
+
+
 def launch_shards(args, argv):
-    """--gpus N: N children, one per GPU, each on its contiguous shard; decided before this process touches a GPU."""
-    from vstnet_amd.sharding import launch_children, rank_environment
+    """--gpus N: N children, one per GPU, each on its contiguous shard; decided before this process touches a GPU (no torch.cuda
+    call here: GPUs are counted from the visible-devices restriction / the KFD topology, vstnet_amd.sharding.count_gpus)."""
+    from vstnet_amd.sharding import launch_children, rank_environment, count_gpus
     n = args.gpus
     base = [a for a in argv]
-    for flag in ("--gpus", "--shard"):                  # children get their own --shard and no --gpus
+    for flag in ("--gpus", "--shard"):                  # children get their own --shard and `--gpus 1`
         while flag in base:
             i = base.index(flag)
             del base[i:i + 2]
     base = [a for a in base if not a.startswith("--gpus=") and not a.startswith("--shard=")]
-    cmds = [[sys.executable, os.path.abspath(__file__)] + base + ["--shard", "%d/%d" % (r, n), "--frames_only"] for r in range(n)]
-    n_dev = torch.cuda.device_count()                   # (counting devices does not initialise HIP; the parent never does)
+    # (the explicit `--gpus 1` comes last and wins whatever survived the rewrite: a child never launches children)
+    cmds = [[sys.executable, os.path.abspath(__file__)] + base + ["--shard", "%d/%d" % (r, n), "--frames_only", "--gpus", "1"]
+            for r in range(n)]
+    # numbered frames of an earlier (longer) run in the children's output directory would fail the merge only after every child
+    # has done its work: they are this script's own outputs, so they go now; anything else in there is left alone
+    frame_dir = os.path.join(args.out_dir, clip_name(args))
+    if os.path.isdir(frame_dir):
+        for f in os.listdir(frame_dir):
+            if FRAME_PNG.match(f):
+                os.remove(os.path.join(frame_dir, f))
+    n_dev = count_gpus()
     return launch_children(cmds, [rank_environment(r, n, visible_device=True, n_devices=n_dev or None) for r in range(n)])
 
 
@@ -123,7 +143,7 @@ def merge_outputs(frame_dir, n_frames, out_dir, name, fps, size):
     """The host side of SURVEY 8(e): the shards wrote frame i as <frame_dir>/%05d.png; check that every index 0..n-1 is there
     exactly once, then — with cv2 — encode the ONE clip <out_dir>/<name>.mp4 in frame order (one lossy encode, like the
     reference's single writer) and drop the PNGs; without cv2 the ordered frame directory is the output."""
-    have = sorted(f for f in os.listdir(frame_dir) if f.endswith(".png"))
+    have = sorted(f for f in os.listdir(frame_dir) if FRAME_PNG.match(f))      # (other files in there are not ours)
     want = ["%05d.png" % i for i in range(n_frames)]
     if have != want:
         missing = sorted(set(want) - set(have))
@@ -142,7 +162,8 @@ def merge_outputs(frame_dir, n_frames, out_dir, name, fps, size):
         writer.release()
     for f in want:
         os.remove(os.path.join(frame_dir, f))
-    os.rmdir(frame_dir)
+    if not os.listdir(frame_dir):
+        os.rmdir(frame_dir)
     return path
 
 
@@ -230,17 +251,22 @@ def main(argv=None):
         frame_dir = os.path.join(args.out_dir, name)
         os.makedirs(frame_dir, exist_ok=True)
 
+    dec_workers, enc_workers = host_workers(args.workers)
+
     def write(i, out):
         if writer is not None:
             writer.write(out[..., ::-1])
         else:
-            Image.fromarray(out).save(os.path.join(frame_dir, "%05d.png" % i))
+            save_png(os.path.join(frame_dir, "%05d.png" % i), out, args.png_level)
 
-    def source():        # decode + resize in a background thread; EVERY frame is resized on its own (video_transfer.py:161)
-        for i in range(lo, hi):
-            yield i, np.asarray(img_resize(frames[i], args.max_size, down_scale=down_scale), dtype=np.uint8)
+    def load(i):         # decode + resize; EVERY frame is resized on its own (video_transfer.py:161)
+        return i, np.asarray(img_resize(frames[i], args.max_size, down_scale=down_scale), dtype=np.uint8)
 
-    sink = AsyncSink(write)
+    def source():        # background threads, frames in order
+        return parallel_map(load, range(lo, hi), workers=dec_workers if isinstance(frames, FrameDir) else 1, ahead=args.depth)
+
+    # numbered PNGs are independent files: encode them on several threads; a video writer takes its frames in order from one
+    sink = AsyncSink(write, ahead=2 * enc_workers, workers=1 if writer is not None else enc_workers)
     try:
         if args.stub_stylise:       # host-logic rehearsal: the "stylised" frame is the resized frame at the writer size
             for i, arr in source():

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void conv_sp_kernel(const SpArgs a) {
                                       res[m_][2 * j_ + 1][0], res[m_][2 * j_ + 1][1], res[m_][2 * j_ + 1][2],                 \
                                       res[m_][2 * j_ + 1][3]};                                                                \
                 u32x4 hi_, lo_;                                                                                               \
-                float unused_;                              /* (range check: at `finish`, once per slice) */                  \
+                float unused_ = 0.f;                        /* (range check: at `finish`, once per slice) */                  \
                 split8_sp(f8_, hi_, lo_, unused_);                                                                            \
                 const int cig_ = pend_cot * 8 + j_ * 4 + kg;                                                                  \
                 if (OUT1) {                                                                                                   \

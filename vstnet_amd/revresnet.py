@@ -84,8 +84,8 @@ class RevResNet(nn.Module):
                 if ch != want:
                     raise ValueError(f"stage {i}: {ch} channels cannot follow {prev} with stride {st} (a stride-2 block squeezes "
                                      "its halves: x4 channels; a stride-1 stage keeps them)")
-                if ch % mult:
-                    raise ValueError(f"stage {i}: channel {ch} must be divisible by mult={mult}")
+                if ch // mult < 1:      # (the reference floors: channel // mult, models/RevResNet.py:81 - no divisibility needed)
+                    raise ValueError(f"stage {i}: channel {ch} // mult {mult} leaves no intermediate channel")
                 prev = ch
             if hidden_dim * 4 ** sp_steps < nChannels[-1] or 2 * nChannels[0] < in_channel:
                 raise ValueError("channel_reduction pad = hidden_dim * 4**sp_steps - nChannels[-1] and the input pad "

@@ -27,12 +27,50 @@ def rank_threads(world: int) -> int:
     return max(1, (os.cpu_count() or 1) // max(1, world))
 
 
+VISIBLE_ENV = ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")
+
+
+def visible_device_list(env=None):
+    """The GPU restriction this process runs under, as the list of device tokens a child may be given, or None if there is
+    none.  HIP_ / CUDA_VISIBLE_DEVICES index into what ROCR_VISIBLE_DEVICES leaves, so the first of HIP_, CUDA_, ROCR_ that is
+    set names the devices as THIS process would number them (the others stay in the child's environment untouched)."""
+    env = os.environ if env is None else env
+    for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = env.get(k)
+        if v is not None and v.strip() != "":
+            return k, [t.strip() for t in v.split(",") if t.strip() != ""]
+    return None, None
+
+
+def count_gpus(env=None, kfd_root="/sys/class/kfd/kfd/topology/nodes") -> int:
+    """GPUs this process may use, WITHOUT touching the HIP / HSA runtime (a parent that is about to start one child per GPU must
+    not initialise a GPU itself): the visible-devices restriction if there is one, else the KFD topology nodes that have SIMDs
+    (CPU nodes have simd_count 0).  0 if neither says anything (not a ROCm host)."""
+    _, lst = visible_device_list(env)
+    if lst is not None:
+        return len(lst)
+    n = 0
+    try:
+        for node in os.listdir(kfd_root):
+            try:
+                for line in open(os.path.join(kfd_root, node, "properties")):
+                    if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                        n += 1
+            except (OSError, ValueError, IndexError):
+                continue
+    except OSError:
+        return 0
+    return n
+
+
 def rank_environment(rank: int, world: int, port: int | None = None, visible_device: bool = False,
                      n_devices: int | None = None) -> dict:
     """Environment of child `rank` of a self-launched node-local job: the torch.distributed.run variables (when a
-    rendezvous port is given), a per-rank CPU thread cap, and — `visible_device` — HIP_VISIBLE_DEVICES so that the child
-    sees exactly its own GPU as device 0 (children that need no rendezvous, e.g. video shards).  n_devices (optional): the
-    node's GPU count; with fewer GPUs than ranks (a rehearsal on a one-GPU box) rank r shares GPU r % n_devices."""
+    rendezvous port is given), a per-rank CPU thread cap, and — `visible_device` — a visible-devices variable so that the child
+    sees exactly its own GPU as device 0 (children that need no rendezvous, e.g. video shards).  A restriction the parent
+    already runs under (HIP_ / CUDA_ / ROCR_VISIBLE_DEVICES = "4,5,6,7") is honoured: child r gets the parent's r-th device,
+    not physical GPU r.  n_devices (optional): the GPU count when there is no such list; with fewer GPUs than ranks (a
+    rehearsal on a one-GPU box) rank r shares GPU r % n."""
     env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     n = str(rank_threads(world))
@@ -41,7 +79,11 @@ def rank_environment(rank: int, world: int, port: int | None = None, visible_dev
     if port is not None:
         env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if visible_device:
-        env["HIP_VISIBLE_DEVICES"] = str(rank % n_devices if n_devices else rank)
+        key, lst = visible_device_list(env)
+        if lst:
+            env[key] = lst[rank % len(lst)]
+        else:
+            env["HIP_VISIBLE_DEVICES"] = str(rank % n_devices if n_devices else rank)
         env["LOCAL_RANK"] = "0"
     return env
 
