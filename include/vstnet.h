@@ -329,9 +329,13 @@ int vst_profile_end_table(int* ids, double* ms, int* launches, int cap, int* n_i
  *                        that keep several frames in flight (video_transfer.py:160-214's loop run on HIP streams);
  *                        0: 8 waves on 16 x 16 tiles, one workgroup per CU (best for one frame at a time).  Results are
  *                        bit-identical.  Initial value: environment variable VST_LEAN (0 / 1), else VST_LEAN_DEFAULT.
+ *   VST_OPT_STAGE3_PINGPONG  diagnostic builds only (-DVST_WITH_PINGPONG=1; VST_E_ARG in the shipped library): the same convs as
+ *                        two wave groups that alternate between a matrix burst and a staging segment (csrc/conv.hip,
+ *                        conv_pp_kernel: measured, bit-identical, not faster).
  * vst_set_option returns VST_E_ARG for an unknown option, vst_get_option the value (or VST_E_ARG).
  * ------------------------------------------------------------------------------------------- */
 #define VST_OPT_STAGE3_LEAN 1
+#define VST_OPT_STAGE3_PINGPONG 2
 int vst_set_option(int option, int value);
 int vst_get_option(int option);
 

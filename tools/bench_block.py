@@ -24,8 +24,14 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--modes", default="bf16x3,f16x2")
     ap.add_argument("--blocks", default="256:1")
+    ap.add_argument("--pingpong", type=int, default=None, help="VST_OPT_STAGE3_PINGPONG for this run")
+    ap.add_argument("--lean", type=int, default=None, help="VST_OPT_STAGE3_LEAN for this run")
     args = ap.parse_args()
     L = _lib.lib()
+    if args.pingpong is not None:
+        _lib.set_option(_lib.OPT_STAGE3_PINGPONG, args.pingpong)
+    if args.lean is not None:
+        _lib.set_option(_lib.OPT_STAGE3_LEAN, args.lean)
     H = W = args.size
     dev = torch.device("cuda", 0)
     modes = {"bf16x3": _lib.PREC_BF16X3, "f16x2": _lib.PREC_F16X2, "f16x2h": _lib.PREC_F16X2H}

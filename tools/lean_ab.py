@@ -27,15 +27,17 @@ def main():
     ap.add_argument("--streams", default="1,2,3,4")
     ap.add_argument("--pairs", type=int, default=2)
     ap.add_argument("--check-sizes", default="1024x1024,200x280,72x40")
+    ap.add_argument("--opt", default="lean", choices=["lean", "pingpong"], help="which option is switched between the two arms")
     ap.add_argument("--steer", action="store_true", help="also time two streams held in anti-phase by events: one stream's "
                     "encode (ending in its stage-3 half) runs against the other's decode (starting with its stage-3 half)")
     args = ap.parse_args()
+    OPT = _lib.OPT_STAGE3_LEAN if args.opt == "lean" else _lib.OPT_STAGE3_PINGPONG
     dev = torch.device("cuda", 0)
     net = RevResNet(precision="bf16x3")
     net.load_state_dict(synthetic_state_dict(1234))
     net = net.to(dev).eval()
     cw = cWCT(precision="bf16x3")
-    out = {"size": args.size, "steps": args.steps, "rates": {}, "bit_identical": {}}
+    out = {"option": args.opt, "size": args.size, "steps": args.steps, "rates": {}, "bit_identical": {}}
     with torch.no_grad():
         # ---- bit-identity of the two forms (same MFMA order per accumulator) -----------------------------------------
         for spec in args.check_sizes.split(","):
@@ -43,7 +45,7 @@ def main():
             xc, xs = synthetic_frames(1, h, w, seed=0).to(dev), synthetic_frames(1, h, w, seed=1).to(dev)
             res = []
             for lean in (0, 1):
-                _lib.set_option(_lib.OPT_STAGE3_LEAN, lean)
+                _lib.set_option(OPT, lean)
                 zc, zs = net(xc), net(xs)
                 zcs = cw.transfer(zc, zs)
                 sty = net(zcs, forward=False)
@@ -51,7 +53,7 @@ def main():
             torch.cuda.synchronize()
             same = all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
             out["bit_identical"][spec] = bool(same)
-            print(f"lean vs 8-wave at {spec}: bit-identical = {same}", flush=True)
+            print(f"{args.opt} vs 8-wave at {spec}: bit-identical = {same}", flush=True)
             assert same, spec
 
         # ---- frame rates ----------------------------------------------------------------------------------------------
@@ -72,7 +74,7 @@ def main():
             torch.cuda.synchronize()
             for pair in range(args.pairs):
                 for lean in (0, 1):
-                    _lib.set_option(_lib.OPT_STAGE3_LEAN, lean)
+                    _lib.set_option(OPT, lean)
                     for i in range(2 * ns):
                         with torch.cuda.stream(streams[i % ns]):
                             frame()
@@ -84,12 +86,12 @@ def main():
                     torch.cuda.synchronize()
                     fps = args.steps / (time.perf_counter() - t0)
                     out["rates"].setdefault(f"streams{ns}_lean{lean}", []).append(round(fps, 2))
-                    print(f"streams {ns} lean {lean}: {fps:7.2f} frames/s", flush=True)
+                    print(f"streams {ns} {args.opt} {lean}: {fps:7.2f} frames/s", flush=True)
         if args.steer:
             sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
             for pair in range(args.pairs):
                 for lean in (0, 1):
-                    _lib.set_option(_lib.OPT_STAGE3_LEAN, lean)
+                    _lib.set_option(OPT, lean)
 
                     def run(n):
                         # stream a: enc(2k) dec(2k) ...; stream b the same one half-frame later: b's encode of frame k starts

@@ -43,6 +43,7 @@ EXPORTS = [
     "vst_set_option", "vst_get_option",
 ]
 OPT_STAGE3_LEAN = 1
+OPT_STAGE3_PINGPONG = 2
 RANGE_SATURATED = 1
 RANGE_WEIGHT = 2
 

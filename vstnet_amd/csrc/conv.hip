@@ -792,6 +792,32 @@ __global__ __launch_bounds__(256, (MID == 16 && TERMS == 2) ? 3 : 1) void conv_p
     VST_TRACE_END_(1, MID, CH)
 }
 
+#ifdef VST_PP_STAMP
+// diagnostic build (-DVST_PP_STAMP=1, tools/pp_stamps.py): s_memtime stamps of one mid-grid workgroup's wave 0 (group X) and wave 4
+// (group Y) around the parts of every stage; never in the shipped library
+__device__ unsigned long long vst_pp_stamps[2 * 32 * 8];
+extern "C" __attribute__((visibility("default"))) int vst_pp_stamps_dump(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vst_pp_stamps), sizeof(vst_pp_stamps));
+}
+#define PP_STAMP(grp_, st_, k_)                                                                                  \
+    if (blockIdx.x == 128 && lane == 0 && (wave & 3) == 0 && (st_) < 32) {                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+        vst_pp_stamps[((grp_) * 32 + (st_)) * 8 + (k_)] = __builtin_amdgcn_s_memtime();                          \
+    }
+// whole-kernel clock of the same workgroup: {s_memtime, s_memrealtime (100 MHz)} at its start and end
+__device__ unsigned long long vst_pp_clk[4];
+extern "C" __attribute__((visibility("default"))) int vst_pp_clk_dump(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vst_pp_clk), sizeof(vst_pp_clk));
+}
+#define PP_CLK(i_)                                                                                               \
+    if (blockIdx.x == 128 && threadIdx.x == 0) {                                                                 \
+        vst_pp_clk[2 * (i_)] = __builtin_amdgcn_s_memtime();                                                     \
+        vst_pp_clk[2 * (i_) + 1] = __builtin_amdgcn_s_memrealtime();                                             \
+    }
+#else
+#define PP_STAMP(grp_, st_, k_)
+#define PP_CLK(i_)
+#endif
 // ---- pipelined kernel for the MFMA-bound shapes: CIN in {64,256}, COUT in {64,256}, stride 1 --------
 // A stage = (32-channel chunk, tap row dy) = 3 k-steps = 144 MFMAs per wave.  Two activation buffers
 // and two weight buffers in LDS; while stage s computes, the wave prefetches stage s+1's weights and a
@@ -834,6 +860,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_pipe_kernel(con
     int bx, by, b;
     if (!xcd_tile(a, bx, by, b)) return;
     VST_TRACE_BEGIN(4)
+    PP_CLK(0)
     const int tx0 = bx * 16, ty0 = by * C::TH;
     const float* const in_img = a.in + (size_t)b * a.in_img_stride;
     float* const out_img = a.out + (size_t)b * a.out_img_stride;
@@ -1074,8 +1101,349 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_pipe_kernel(con
 #undef STORE_B
 #undef F4_
 #undef RS
+    PP_CLK(1)
     VST_TRACE_END_(4, CIN, COUT)
 }
+
+#ifndef VST_WITH_PINGPONG
+#define VST_WITH_PINGPONG 0          // 1 (tools/ab_build.py ... -DVST_WITH_PINGPONG=1): compile conv_pp_kernel, selectable by VST_OPT_STAGE3_PINGPONG
+#endif
+#if VST_WITH_PINGPONG
+// ---- ping-pong form of the pipelined kernel (VST_OPT_STAGE3_PINGPONG) -------------------------------------------------------
+// Same tile, LDS images, fragments and MFMA order per accumulator as conv_pipe_kernel (bit-identical results); what changes is
+// WHEN the two waves of a SIMD do what.  In conv_pipe_kernel all eight waves pass every stage in lockstep: they land data,
+// read their first fragments and wait together (matrix pipe idle: ~2 000 of a stage's ~4 300 cycles), then share the pipe.  Here
+// the workgroup is two groups of four waves, one wave per SIMD each - X = waves 0-3 (tile rows 0-7), Y = waves 4-7 (rows 8-15;
+// wave w and w + 4 share a SIMD) - that alternate: while X issues its 72 MFMAs of stage s back to back, Y does everything that
+// is not matrix work (landing the staged weights / activations in LDS, issuing the next global loads, the read-modify-write
+// traffic of its output rows, reading its first fragments of stage s); one barrier; then Y computes stage s while X reads its
+// first fragments of stage s + 1 and moves its output rows.  Half-steps h = 0, 1, 2, ...: X computes stage s at h = 2s, Y at
+// h = 2s + 1.  LDS hazards, one barrier per half-step:
+//   * weights of stage s + 1 go to B[(s+1)&1] at h = 2s (by Y): last read at h = 2s - 1 (Y, stage s - 1), first read by X's
+//     fragment prefetch at h = 2s + 1;
+//   * activations of chunk c + 1 go to A[(c+1)&1] in thirds at h = 6c, 6c + 2, 6c + 4 (by Y): last read at h = 6c - 1 (Y, chunk
+//     c - 1), first read at h = 6c + 5 (X's prefetch for stage 3(c+1)).
+// All staging is done by Y (its segment runs beside X's MFMA burst; X's segment beside Y's burst holds only the fragment
+// prefetch and X's share of the epilogue), so every fragment a burst starts with is in registers before the barrier.
+// Measured (round 4, profiles/r04_pingpong.json): bit-identical, and NOT faster - 58.1 / 22.5 / 54.0 us against 56.9 / 20.9 / 52.2
+// for 256->64 / 64->64 / 64->256.  In-kernel stamps: a burst of 72 MFMAs takes 1 450 - 1 600 cycles (1 152 at the pipe's rate) with
+// the partner's segment beside it, a stage 3 300 - 3 600 cycles - what conv_pipe_kernel's lockstep stage takes as well: the SIMD's
+// instruction issue (MFMA 8 of every 16 cycles, the fragment reads, the partner's ~150 staging instructions), not the order of
+// the phases, is what a stage costs.  Kept out of the shipped library (VST_WITH_PINGPONG = 0).
+template <int CIN, int COUT, bool IN_STATE, bool OUT_STATE>
+__global__ __launch_bounds__(512) void conv_pp_kernel(const ConvArgs a) {
+    using C = PipeCfg<CIN, COUT, 8>;
+    constexpr int SY = 256;                                                  // staging threads (group Y)
+    constexpr int A_ITEMS_Y = ((C::A_PART / 4 + 15) / 16 * 64 + SY - 1) / SY;   // (slot, cig) items per Y thread and part: 2
+    constexpr int B_ITEMS_Y = 2 * 768 / SY;                                  // uint4 per Y thread and stage: 6
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const Abuf = smem;
+    unsigned char* const Bbuf = smem + 2 * C::A_BUF;
+    float* const bias_lds = (float*)(smem + C::LDS_BYTES);                  // (the sliced kernel: COUT floats behind the buffers)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 15, kg = lane >> 4;
+    const bool grpY = wave >= 4;                                             // wave-uniform
+    int bx, by, b;
+    if (!xcd_tile(a, bx, by, b)) return;
+    VST_TRACE_BEGIN(4)
+    PP_CLK(0)
+    const int tx0 = bx * 16, ty0 = by * C::TH;
+    const float* const in_img = a.in + (size_t)b * a.in_img_stride;
+    float* const out_img = a.out + (size_t)b * a.out_img_stride;
+    const PackedConvLayout PL = packed_conv_layout(COUT, CIN);
+    const unsigned char* const w_plane0 = a.packed + PL.f32_bytes;
+    constexpr int Q = C::NCOT * C::NCHUNK, S = 3 * Q;                        // (slice, chunk) pairs; stages
+    // 256-channel inputs stream their eight chunk images through the two buffers inside the loop (group Y stages them); the
+    // two chunk images of a 64-channel input (h1 / h2) are both staged by the prologue and stay: no activation traffic, staging
+    // registers or address tables in the loop of the 64 -> 64 and 64 -> 256 convs
+    constexpr bool A_IN_LOOP = C::NCHUNK > 2;
+
+#define PP_A_ADDR(j_, part_, src_, dst_)                                                                         \
+    {                                                                                                            \
+        int sl_ = ((j_) >> 6) * 16 + ((j_) & 15);                                                                \
+        sl_ = sl_ < C::A_PART / 4 ? sl_ : C::A_PART / 4 - 1;                                                     \
+        const int cig_ = ((j_) >> 4) & 3, slot_ = (part_) * (C::A_PART / 4) + sl_;                               \
+        const int iy_ = slot_ / C::IW, ix_ = slot_ - iy_ * C::IW;                                                \
+        const int gy_ = reflect_clamp(ty0 - 1 + iy_, a.Hin), gx_ = reflect_clamp(tx0 - 1 + ix_, a.Win);          \
+        const size_t off_ = IN_STATE ? zc_offset(vst_level_of_channels(CIN), gy_, gx_, a.Wq)                     \
+                                     : ((size_t)gy_ * a.Win + gx_) * CIN;                                        \
+        src_ = (unsigned)(off_ + cig_ * 8);                                                                      \
+        dst_ = (cig_ * C::NSLOT + slot_) * 16;                                                                   \
+    }
+#define PP_F4(v_) make_float4((v_)[0], (v_)[1], (v_)[2], (v_)[3])
+#define PP_LAND_A(base_, r0_, r1_, dst_)                                                                         \
+    {                                                                                                            \
+        uint4 h_, l_;                                                                                            \
+        split8(PP_F4(r0_), PP_F4(r1_), h_, l_);                                                                  \
+        *(uint4*)((base_) + (dst_)) = h_;                                                                        \
+        *(uint4*)((base_) + C::A_PLANE + (dst_)) = l_;                                                           \
+    }
+    // ---- prologue (all eight waves): chunk 0's image and stage 0's weights --------------------------------------------------
+    if constexpr (OUT_STATE) {                   // the bias of all four slices waits in LDS (16 registers less in the loop)
+        if (tid < COUT / 4) *(float4*)(bias_lds + 4 * tid) = *(const float4*)(a.bias + 4 * tid);
+    }
+    {
+        u32x4 wb[3];
+        f32x4 r[3][2];
+        unsigned dsta[3];
+        int dstb[3];
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int idx = it * 512 + tid;
+            const int plane = idx >= 768, rr = idx - plane * 768;
+            const int k3 = rr >> 8, kgi = (rr >> 6) & 3, co = rr & 63;
+            wb[it] = *(const u32x4*)(w_plane0 + (size_t)(plane * PL.frag_bytes) + ((k3 * 4 + kgi) * COUT + co) * 16);
+            dstb[it] = plane * C::B_PLANE + rr * 16;
+        }
+        // two-chunk inputs (h1 / h2): the second chunk's image as well - in the same burst of loads where the registers allow it
+        // (the 64 -> 256 conv's loop is at the register limit: it lands chunk 0 first and reuses the registers)
+        constexpr bool BURST2 = !A_IN_LOOP && !OUT_STATE;
+        f32x4 r1[BURST2 ? 3 : 1][2];
+        unsigned srca[3];
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+            PP_A_ADDR(tid, part, srca[part], dsta[part]);
+            const float* p = in_img + srca[part];
+            r[part][0] = *(const f32x4*)p;
+            r[part][1] = *(const f32x4*)(p + 4);
+            if constexpr (BURST2) {
+                r1[part][0] = *(const f32x4*)(p + 32);
+                r1[part][1] = *(const f32x4*)(p + 36);
+            }
+        }
+#pragma unroll
+        for (int part = 0; part < 3; ++part) PP_LAND_A(Abuf, r[part][0], r[part][1], dsta[part]);
+#pragma unroll
+        for (int it = 0; it < 3; ++it) *(u32x4*)(Bbuf + dstb[it]) = wb[it];
+        if constexpr (BURST2) {
+#pragma unroll
+            for (int part = 0; part < 3; ++part) PP_LAND_A(Abuf + C::A_BUF, r1[part][0], r1[part][1], dsta[part]);
+        } else if constexpr (!A_IN_LOOP) {
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+                const float* p = in_img + srca[part] + 32;
+                r[part][0] = *(const f32x4*)p;
+                r[part][1] = *(const f32x4*)(p + 4);
+            }
+#pragma unroll
+            for (int part = 0; part < 3; ++part) PP_LAND_A(Abuf + C::A_BUF, r[part][0], r[part][1], dsta[part]);
+        }
+    }
+    // ---- group Y's staging state: addresses of its items, one register set (landed, then reloaded, in every Y segment) ------
+    const int ty = tid & (SY - 1);
+    unsigned a_src[A_IN_LOOP ? 3 : 1][A_ITEMS_Y], a_dst[A_IN_LOOP ? 3 : 1][A_ITEMS_Y];
+    if constexpr (A_IN_LOOP) {
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+#pragma unroll
+            for (int it = 0; it < A_ITEMS_Y; ++it) PP_A_ADDR(it * SY + ty, part, a_src[part][it], a_dst[part][it]);
+    }
+    const int b_off0 = ((ty >> 6) * COUT + (ty & 63)) * 16, b_dst0 = ty * 16;     // item it = (plane it / 3, k-step it % 3)
+    u32x4 rb[B_ITEMS_Y];
+    f32x4 ra[A_ITEMS_Y][2];
+#define PP_LOAD_B(st_)                                                                                           \
+    {                                                                                                            \
+        const int q_ = (st_) / 3, dy_ = (st_) - 3 * q_, cot_ = q_ / C::NCHUNK, chunk_ = q_ - cot_ * C::NCHUNK;   \
+        const unsigned char* src_ = w_plane0 + ((size_t)(chunk_ * 9 + dy_ * 3) * 4 * COUT + cot_ * 64) * 16 + b_off0;   \
+        _Pragma("unroll") for (int it_ = 0; it_ < B_ITEMS_Y; ++it_)                                              \
+            rb[it_] = *(const u32x4*)(src_ + (size_t)(it_ / 3) * PL.frag_bytes + (it_ % 3) * 4 * COUT * 16);     \
+    }
+#define PP_STORE_B(buf_)                                                                                         \
+    _Pragma("unroll") for (int it_ = 0; it_ < B_ITEMS_Y; ++it_)                                                  \
+        *(u32x4*)(Bbuf + (buf_) * C::B_BUF + b_dst0 + (it_ / 3) * C::B_PLANE + (it_ % 3) * 256 * 16) = rb[it_];
+#define PP_LOAD_A(chunk_, part_)                                                                                 \
+    _Pragma("unroll") for (int it_ = 0; it_ < A_ITEMS_Y; ++it_) {                                                \
+        const float* p_ = in_img + a_src[part_][it_] + (chunk_) * 32;                                            \
+        ra[it_][0] = *(const f32x4*)p_; ra[it_][1] = *(const f32x4*)(p_ + 4);                                    \
+    }
+#define PP_STORE_A(buf_, part_)                                                                                  \
+    _Pragma("unroll") for (int it_ = 0; it_ < A_ITEMS_Y; ++it_)                                                  \
+        PP_LAND_A(Abuf + (buf_) * C::A_BUF, ra[it_][0], ra[it_][1], a_dst[part_][it_])
+    if (grpY) {                                  // what Y lands in its first segment (h = 0): stage 1's weights, chunk 1's first third
+        PP_LOAD_B(1);
+        if constexpr (A_IN_LOOP) { PP_LOAD_A(1, 0); }
+    }
+#define PP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    PP_BARRIER();
+
+    // fragments: the pixel operands of a k-step (xh, xl for the wave's two tile rows) are double-buffered per k-step, the weight
+    // operands stream per 16-channel block n through a ring of three (step t = 4 k3 + n reads slot t % 3; the read of step t + 2
+    // is issued before the six MFMAs of step t) - 56 registers where whole k-steps double-buffered take 96
+    bf16x8 fxh[2][C::MR], fxl[2][C::MR], fwh[3], fwl[3];
+#define PP_READ_X(buf_, Ab_, k3_)                                                                                \
+    _Pragma("unroll") for (int m_ = 0; m_ < C::MR; ++m_) {                                                       \
+        fxh[buf_][m_] = __builtin_bit_cast(bf16x8, *(const uint4*)((Ab_) + (m_ * C::IW + (k3_)) * 16));          \
+        fxl[buf_][m_] = __builtin_bit_cast(bf16x8, *(const uint4*)((Ab_) + C::A_PLANE + (m_ * C::IW + (k3_)) * 16));   \
+    }
+#define PP_READ_W(slot_, Bb_, t_)                                                                                \
+    {                                                                                                            \
+        fwh[slot_] = __builtin_bit_cast(bf16x8, *(const uint4*)((Bb_) + (((t_) >> 2) * 256 + ((t_) & 3) * 16) * 16));   \
+        fwl[slot_] = __builtin_bit_cast(bf16x8, *(const uint4*)((Bb_) + C::B_PLANE + (((t_) >> 2) * 256 + ((t_) & 3) * 16) * 16));   \
+    }
+    // what a burst starts with: the pixel operands of k-step 0 and the weight operands of steps 0 and 1 (read in the segment
+    // BEFORE the barrier that opens the burst)
+#define PP_PREFETCH(st_)                                                                                         \
+    {                                                                                                            \
+        const unsigned char* Ab_ = PP_AB(st_);                                                                   \
+        const unsigned char* Bb_ = PP_BB(st_);                                                                   \
+        PP_READ_X(0, Ab_, 0);                                                                                    \
+        PP_READ_W(0, Bb_, 0);                                                                                    \
+        PP_READ_W(1, Bb_, 1);                                                                                    \
+    }
+    const int slot_base = (wave * C::MR) * C::IW + lrow;
+    const int oy0 = ty0 + wave * C::MR;
+    const unsigned a_lane = (kg * C::NSLOT + slot_base) * 16, b_lane = (kg * 64 + lrow) * 16;
+    // LDS addresses of stage st's operands for this lane
+#define PP_AB(st_) (Abuf + ((((st_) / 3) % C::NCHUNK) & 1) * C::A_BUF + a_lane + ((st_) % 3) * C::IW * 16)
+#define PP_BB(st_) (Bbuf + ((st_) & 1) * C::B_BUF + b_lane)
+
+    f32x4 acc[C::MR][4];
+#pragma unroll
+    for (int m = 0; m < C::MR; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 bias[4], old[C::MR][4];
+    const bool full_tile = ty0 + C::TH <= a.Hout && tx0 + 16 <= a.Wout;     // uniform: interior tiles skip all predicates
+    constexpr bool SLICED = OUT_STATE && C::NCOT > 1;                        // the 64 -> 256 conv: four 64-channel output slices
+    static_assert(!OUT_STATE || (C::NCOT > 1 && C::NCHUNK == 2), "read-modify-write epilogue: the 64 -> 256 conv");
+    bool pending = false;                                                    // `old` holds a finished slice whose stores are due
+    int pend_cot = 0;
+    // the matrix burst of stage st: 12 steps (k-step k3, channel block n) of 6 MFMAs
+#define PP_COMPUTE(st_)                                                                                          \
+    {                                                                                                            \
+        const unsigned char* Ab_ = PP_AB(st_);                                                                   \
+        const unsigned char* Bb_ = PP_BB(st_);                                                                   \
+        __builtin_amdgcn_s_setprio(1);                                                                           \
+        _Pragma("unroll") for (int t = 0; t < 12; ++t) {                                                         \
+            const int k3 = t >> 2, n = t & 3;                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            if (n == 0 && k3 < 2) PP_READ_X((k3 + 1) & 1, Ab_, k3 + 1);                                          \
+            if (t + 2 < 12) PP_READ_W((t + 2) % 3, Bb_, t + 2);                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            _Pragma("unroll") for (int m = 0; m < C::MR; ++m) { MFMA3(acc[m][n], fwh[t % 3], fwl[t % 3], fxh[k3 & 1][m], fxl[k3 & 1][m]); }   \
+        }                                                                                                        \
+        __builtin_amdgcn_s_setprio(0);                                                                           \
+    }
+    // the 64 -> 256 conv's epilogue, spread over the group's own staging segments.  j = stage within the slice (0..5):
+    //   a slice's results are formed in place in `old` (old + sign * (acc + bias)) once its last burst is done, and leave - two
+    //   units (m, n) per segment - during the next slice's first four segments, each followed by the load of the same unit's
+    //   old state value of the new slice (in flight for two segments or more before it is used)
+#define PP_FINISH(cot_)                                                                                          \
+    {                                                                                                            \
+        _Pragma("unroll") for (int n = 0; n < 4; ++n) bias[n] = *(const float4*)(bias_lds + (cot_) * 64 + 4 * kg + n * 16);   \
+        _Pragma("unroll") for (int m = 0; m < C::MR; ++m)                                                        \
+            _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                                      \
+                const float4 o = old[m][n];                                                                      \
+                old[m][n] = make_float4(o.x + a.sign * (acc[m][n][0] + bias[n].x), o.y + a.sign * (acc[m][n][1] + bias[n].y),   \
+                                        o.z + a.sign * (acc[m][n][2] + bias[n].z), o.w + a.sign * (acc[m][n][3] + bias[n].w));  \
+                acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};                                                           \
+            }                                                                                                    \
+        pending = true;                                                                                          \
+        pend_cot = (cot_);                                                                                       \
+    }
+#define PP_UNITS(j_, cot_)                                                                                       \
+    if ((j_) < 4) {                                                                                              \
+        _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                                       \
+            const int unit = 2 * (j_) + u_, m_ = unit >> 2, n_ = unit & 3;                                       \
+            if (pending) {                                                                                       \
+                float4* p_ = full_tile ? out_ptr<COUT, true, true>(a, out_img, oy0 + m_, tx0 + lrow, pend_cot * 64 + 4 * kg + n_ * 16)   \
+                                       : out_ptr<COUT, true, false>(a, out_img, oy0 + m_, tx0 + lrow, pend_cot * 64 + 4 * kg + n_ * 16); \
+                if (full_tile || p_) *p_ = old[m_][n_];                                                          \
+            }                                                                                                    \
+            const float4* q_ = full_tile ? out_ptr<COUT, true, true>(a, out_img, oy0 + m_, tx0 + lrow, (cot_) * 64 + 4 * kg + n_ * 16)   \
+                                         : out_ptr<COUT, true, false>(a, out_img, oy0 + m_, tx0 + lrow, (cot_) * 64 + 4 * kg + n_ * 16); \
+            old[m_][n_] = (full_tile || q_) ? *q_ : make_float4(0.f, 0.f, 0.f, 0.f);                             \
+        }                                                                                                        \
+        if ((j_) == 3) pending = false;                                                                          \
+    }
+    if (!grpY) { PP_PREFETCH(0); }                                             // X's first burst starts at once
+
+    // (two (slice, chunk) pairs per loop body: the chunk's parity - the activation buffer, and for the sliced kernel the stage's
+    // position j in its slice, which picks the epilogue units - is then a compile-time constant)
+    static_assert(Q % 2 == 0 && C::NCHUNK % 2 == 0, "two (slice, chunk) pairs per loop body");
+#pragma unroll 1
+    for (int q0 = 0; q0 < Q; q0 += 2) {
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const int q = q0 + qq;
+        const int cot = q / C::NCHUNK, chunk = q - cot * C::NCHUNK;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int s = q * 3 + dy;
+            const int j = (C::NCHUNK == 2 ? qq * 3 : 0) + dy;               // stage within the output slice (SLICED kernels)
+            if (!grpY) {
+                // ================= X: burst of stage s, then its segment beside Y's burst =================================
+                PP_STAMP(0, s, 0)
+                PP_COMPUTE(s);
+                PP_STAMP(0, s, 1)
+                PP_BARRIER();
+                PP_STAMP(0, s, 2)
+                if (s + 1 < S) { PP_PREFETCH(s + 1); }
+                if constexpr (SLICED) {
+                    PP_UNITS(j, cot);
+                    if (j == 5 && cot < C::NCOT - 1) { PP_FINISH(cot); }
+                }
+                PP_STAMP(0, s, 3)
+                PP_BARRIER();
+            } else {
+                // ================= Y: its segment beside X's burst of stage s, then its own burst =========================
+                PP_STAMP(1, s, 0)
+                PP_PREFETCH(s);
+                if (s + 1 < S) { PP_STORE_B((s + 1) & 1); }
+                if constexpr (A_IN_LOOP) {
+                    if (q < C::NCHUNK - 1) { PP_STORE_A((chunk + 1) & 1, dy); }
+                }
+                PP_STAMP(1, s, 1)
+                if (s + 2 < S) { PP_LOAD_B(s + 2); }
+                if constexpr (A_IN_LOOP) {   // the activations landed in the NEXT Y segment (stage s + 1 = (q1, dy1)): part dy1 of chunk(q1) + 1
+                    const int q1 = dy == 2 ? q + 1 : q, dy1 = (dy + 1) % 3;
+                    if (q1 < C::NCHUNK - 1) { PP_LOAD_A(q1 + 1, dy1); }
+                }
+                if constexpr (SLICED) {
+                    if (j == 0 && cot > 0) { PP_FINISH(cot - 1); }
+                    PP_UNITS(j, cot);
+                }
+                PP_STAMP(1, s, 2)
+                PP_BARRIER();
+                PP_STAMP(1, s, 3)
+                PP_COMPUTE(s);
+                PP_STAMP(1, s, 4)
+                PP_BARRIER();
+            }
+        }
+      }
+    }
+    // ---- the last output slice (or the only one) ------------------------------------------------------------------------------
+    if constexpr (SLICED) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bias[n] = *(const float4*)(bias_lds + (C::NCOT - 1) * 64 + 4 * kg + n * 16);
+    } else {
+        load_bias<COUT, 4>(a, 4 * kg, bias);
+    }
+    if (full_tile) store_tile<COUT, OUT_STATE, C::MR, 4, true>(a, out_img, oy0, tx0 + lrow, (C::NCOT - 1) * 64 + 4 * kg, acc, bias, old);
+    else store_tile<COUT, OUT_STATE, C::MR, 4, false>(a, out_img, oy0, tx0 + lrow, (C::NCOT - 1) * 64 + 4 * kg, acc, bias, old);
+#undef PP_A_ADDR
+#undef PP_F4
+#undef PP_LAND_A
+#undef PP_LOAD_B
+#undef PP_STORE_B
+#undef PP_LOAD_A
+#undef PP_STORE_A
+#undef PP_BARRIER
+#undef PP_AB
+#undef PP_BB
+#undef PP_COMPUTE
+#undef PP_READ_X
+#undef PP_READ_W
+#undef PP_PREFETCH
+#undef PP_FINISH
+#undef PP_UNITS
+    PP_CLK(1)
+    VST_TRACE_END_(4, CIN, COUT)
+}
+
+#endif  // VST_WITH_PINGPONG
 
 // Diagnostic fp32 direct convolution (VST_PREC_FP32): one thread per (pixel, co), plain FMA chain.
 template <bool IN_STATE, bool OUT_STATE>
@@ -1140,6 +1508,11 @@ void vst_prof_close(int rec, hipStream_t st) {
 #endif
 static std::atomic<int> g_opt_lean{[] { const char* e = getenv("VST_LEAN"); return e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : VST_LEAN_DEFAULT; }()};
 static bool vst_lean_stage3() { return g_opt_lean.load(std::memory_order_relaxed) != 0; }
+// VST_OPT_STAGE3_PINGPONG (vstnet.h): conv_pp_kernel instead of conv_pipe_kernel
+#ifndef VST_PINGPONG_DEFAULT
+#define VST_PINGPONG_DEFAULT 0
+#endif
+static std::atomic<int> g_opt_pp{[] { const char* e = getenv("VST_PINGPONG"); return e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : VST_PINGPONG_DEFAULT; }()};
 
 template <int CIN, int COUT, int STRIDE, bool IN_STATE, bool OUT_STATE>
 static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st, bool out_h16 = false) {
@@ -1164,6 +1537,17 @@ static int launch_conv(const ConvArgs& a, int B, int precision, hipStream_t st, 
             t.tiles_y = (a.Hout + C::TH - 1) / C::TH; t.tiles_total = t.tiles_x * t.tiles_y * B;
             VST_TRACE_RESERVE(t, (t.tiles_total + 7) / 8 * 8)
             kern<<<dim3((t.tiles_total + 7) / 8 * 8), C::NTHR, C::LDS_BYTES, st>>>(t);
+#if VST_WITH_PINGPONG
+        } else if (g_opt_pp.load(std::memory_order_relaxed)) {
+            using C = PipeCfg<CIN, COUT>;
+            auto kern = conv_pp_kernel<CIN, COUT, IN_STATE, OUT_STATE>;
+            constexpr int lds = C::LDS_BYTES + (OUT_STATE ? COUT * 4 : 0);       // (+ the bias of the sliced kernel)
+            static std::atomic<unsigned> attr_done{0};
+            if (int rc_ = vst_ensure_dynamic_lds((const void*)kern, lds, &attr_done)) return rc_;
+            t.tiles_y = (a.Hout + C::TH - 1) / C::TH; t.tiles_total = t.tiles_x * t.tiles_y * B;
+            VST_TRACE_RESERVE(t, (t.tiles_total + 7) / 8 * 8)
+            kern<<<dim3((t.tiles_total + 7) / 8 * 8), C::NTHR, lds, st>>>(t);
+#endif
         } else {
             using C = PipeCfg<CIN, COUT>;
             auto kern = conv_pipe_kernel<CIN, COUT, IN_STATE, OUT_STATE>;
@@ -1329,14 +1713,16 @@ VST_DEFINE_TU_RANGE(vst_range_tu_conv)
 extern "C" {
 
 int vst_set_option(int option, int value) {
-    if (option != VST_OPT_STAGE3_LEAN) return VST_E_ARG;
-    g_opt_lean.store(value != 0, std::memory_order_relaxed);
+    if (option == VST_OPT_STAGE3_LEAN) g_opt_lean.store(value != 0, std::memory_order_relaxed);
+    else if (option == VST_OPT_STAGE3_PINGPONG && VST_WITH_PINGPONG) g_opt_pp.store(value != 0, std::memory_order_relaxed);
+    else return VST_E_ARG;
     return VST_OK;
 }
 
 int vst_get_option(int option) {
-    if (option != VST_OPT_STAGE3_LEAN) return VST_E_ARG;
-    return g_opt_lean.load(std::memory_order_relaxed);
+    if (option == VST_OPT_STAGE3_LEAN) return g_opt_lean.load(std::memory_order_relaxed);
+    if (option == VST_OPT_STAGE3_PINGPONG && VST_WITH_PINGPONG) return g_opt_pp.load(std::memory_order_relaxed);
+    return VST_E_ARG;
 }
 
 int vst_range_flags(unsigned* flags_host, int reset) {
