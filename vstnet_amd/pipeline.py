@@ -186,16 +186,11 @@ def parallel_map(fn, items, workers=4, ahead=8):
 
 
 def host_cores():
-    """cores this process may use: affinity mask, capped by the cgroup quota and by the per-rank thread cap that
+    """cores this process may use: the usable cores (affinity mask, cgroup quota), capped by the per-rank thread cap that
     launch_children sets in OMP_NUM_THREADS"""
     import os
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
-    except (OSError, ValueError):
-        pass
+    from .sharding import usable_cores
+    n = usable_cores()
     if os.environ.get("OMP_NUM_THREADS", "").isdigit():
         n = min(n, int(os.environ["OMP_NUM_THREADS"]))
     return max(1, n)

@@ -20,11 +20,24 @@ def shard_range(n_frames: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def usable_cores() -> int:
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box exposes every host core in
+    os.cpu_count() but schedules a job on its share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def rank_threads(world: int) -> int:
-    """CPU threads one rank of `world` may use on this host: the ranks of a node share its cores, and N ranks x torch's
+    """CPU threads one rank of `world` may use on this host: the ranks of a node share its usable cores, and N ranks x torch's
     default intra-op pool (one thread per core each) is the oversubscription that throttled the feeding thread once
     (vstnet_amd/pipeline.py)."""
-    return max(1, (os.cpu_count() or 1) // max(1, world))
+    return max(1, usable_cores() // max(1, world))
 
 
 VISIBLE_ENV = ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")
