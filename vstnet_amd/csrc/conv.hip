@@ -975,6 +975,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_pipe_kernel(con
     const int slot_base = (wave * C::MR) * C::IW + lrow;
     const int oy0 = ty0 + wave * C::MR;
     float4 bias[4], old[C::MR][4];
+#if VST_ABLATE & 8
+    f32x16 abl_big[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { abl_big[0][i] = 0.f; abl_big[1][i] = 0.f; }
+#endif
     const bool full_tile = ty0 + C::TH <= a.Hout && tx0 + 16 <= a.Wout; // uniform: interior tiles skip all predicates
     // Kernels that loop several 64-channel output slices (the 64 -> 256 conv: four) DEFER a slice's stores: at the slice's end
     // the results are formed in place in `old` (old + sign * (acc + bias)), and the eight float4 stores per lane go out one per
@@ -1056,10 +1061,24 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_pipe_kernel(con
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const Frags& f = fr[(VST_ABLATE & 1) ? 0 : (k3 & 1)];
+#if VST_ABLATE & 8
+                // timing-only (wrong results): the k-step's 24 v_mfma_f32_16x16x32 as 12 v_mfma_f32_32x32x16 on the same
+                // fragment registers - the same matrix-pipe cycles with half the MFMA instructions (is the stage issue-bound?)
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    abl_big[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wh[2 * jb], f.xl[0], abl_big[jb], 0, 0, 0);
+                    abl_big[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wl[2 * jb], f.xh[0], abl_big[jb], 0, 0, 0);
+                    abl_big[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wh[2 * jb], f.xh[0], abl_big[jb], 0, 0, 0);
+                    abl_big[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wh[2 * jb + 1], f.xl[1], abl_big[jb], 0, 0, 0);
+                    abl_big[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wl[2 * jb + 1], f.xh[1], abl_big[jb], 0, 0, 0);
+                    abl_big[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wh[2 * jb + 1], f.xh[1], abl_big[jb], 0, 0, 0);
+                }
+#else
 #pragma unroll
                 for (int m = 0; m < C::MR; ++m)
 #pragma unroll
                     for (int n = 0; n < 4; ++n) { MFMA3(acc[m][n], f.wh[n], f.wl[n], f.xh[m], f.xl[m]); }
+#endif
             }
 
             // ---- output tile of this 64-channel slice ------------------------------------------------------------
@@ -1101,6 +1120,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_pipe_kernel(con
 #undef STORE_B
 #undef F4_
 #undef RS
+#if VST_ABLATE & 8
+    asm volatile("" :: "v"(abl_big[0]), "v"(abl_big[1]));
+#endif
     PP_CLK(1)
     VST_TRACE_END_(4, CIN, COUT)
 }
