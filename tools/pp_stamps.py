@@ -25,7 +25,8 @@ args = ap.parse_args()
 L = _lib.lib()
 L.vst_pp_stamps_dump.restype = C.c_int
 L.vst_pp_stamps_dump.argtypes = [C.c_void_p]
-_lib.set_option(_lib.OPT_STAGE3_PINGPONG, args.pingpong)
+if args.pingpong:
+    _lib.set_option(_lib.OPT_STAGE3_PINGPONG, 1)          # (needs a -DVST_WITH_PINGPONG=1 build)
 L.vst_pp_clk_dump.restype = C.c_int
 L.vst_pp_clk_dump.argtypes = [C.c_void_p]
 H = W = args.size
@@ -48,7 +49,7 @@ clk = np.zeros(4, dtype=np.uint64)
 assert L.vst_pp_clk_dump(clk.ctypes.data_as(C.c_void_p)) == 0
 clk = clk.astype(np.int64)
 cyc, ticks = clk[2] - clk[0], clk[3] - clk[1]
-print(f"last stage-3 launch (conv.7), pingpong={args.pingpong}, after {args.reps} blocks back to back: workgroup 128 took {cyc} shader cycles in "
+print(f"{os.environ.get('VSTNET_HIP_LIB', 'shipped library').split('/')[-1]}: last stage-3 launch (conv.7), pingpong={args.pingpong}, after {args.reps} blocks back to back: workgroup 128 took {cyc} shader cycles in "
       f"{ticks * 10} ns -> in-kernel clock {cyc / max(ticks, 1) * 0.1:.3f} GHz")
 if not args.pingpong:
     sys.exit(0)

@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_pipe_kernel(con
 #pragma unroll
                     for (int n = 0; n < 4; ++n) asm volatile("" : "+v"(acc[m][n]));
             }
-            __syncthreads();
+            if (!(VST_ABLATE & 16)) __syncthreads();                // (ablation 16, timing-only: no stage barrier)
         }
       }
     }
