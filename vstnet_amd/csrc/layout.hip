@@ -304,7 +304,7 @@ VST_DEFINE_TU_RANGE(vst_range_tu_layout)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int vst_version(void) { return 101; }
+int vst_version(void) { return 102; }
 
 int vst_normalize_block(float* w1, float* b1, float* w4, float* b4, float* w7, int c_in1, int c_mid, int c_out, float* scales,
                         void* stream) {
