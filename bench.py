@@ -27,6 +27,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_COPY_GBS = 6290.0          # the same guide's measured float4 copy rate: SURVEY 8(d)'s "second denominator"
 MFMA_16BIT_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak
 PMC_FILE = "r04_pmc_hbm_traffic.json"   # committed rocprofv3 --pmc summary that `roofline.traffic` is read from (never measured live)
 
@@ -303,7 +304,8 @@ def main():
         "per_rank": {"frames_per_s": per_rank_fps, "min": min(per_rank_fps), "max": max(per_rank_fps)},
         "frame_hbm_roofline": {"bound": "hbm", "algorithmic_bytes_per_frame": frame_bytes,
                                "achieved": round(frame_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(frame_gbs / HBM_PEAK_GBS, 4), "per": "GPU"},
+                               "frac": round(frame_gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy_rate": round(frame_gbs / HBM_COPY_GBS, 4),
+                               "measured_copy_rate": HBM_COPY_GBS, "per": "GPU"},
     }
     if rank == 0 and table:
         rec["roofline"], rec["stages"], rec["kernel_classes"], rec["frame_level"] = roofline_from_table(
@@ -523,6 +525,7 @@ def roofline_from_table(table, n_frames, fpg, H, W, args, _lib, ms_per_step=None
         if ms_per_step:
             frame["chip_average_pmc_TBps"] = round(pmc_frame / (ms_per_step * 1e-3) / 1e12, 3)
             frame["chip_average_pmc_frac_of_hbm_peak"] = round(pmc_frame / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            frame["chip_average_pmc_frac_of_measured_copy_rate"] = round(pmc_frame / (ms_per_step * 1e-3) / 1e9 / HBM_COPY_GBS, 4)
     frame["note"] = ("pmc_bytes_per_frame = sum over this run's launches per frame (HIP-event table) x HBM bytes per launch of the committed "
                      "PMC summary; chip averages divide by the timed region's ms per frame (frames in flight on several streams); "
                      "overlap_of_kernel_time = 1 - ms per frame / sum of kernel times of a frame run alone")
