@@ -964,16 +964,18 @@ def test_full_size_config5_1080p_masked(kind, precision):
         assert int(dd.max()) <= 1 and float((dd > 0).float().mean()) < (1e-3 if precision == "bf16x3" else 2e-2)
 
 
-@pytest.mark.parametrize("shape", [(1024, 1024), (200, 280), (72, 40)])
-def test_stage3_lean_option_is_bit_identical(shape):
+@pytest.mark.parametrize("mode,batch,shape", [("photo", 1, (1024, 1024)), ("photo", 1, (200, 280)), ("photo", 1, (72, 40)),
+                                              ("art", 3, (136, 104)), ("photo", 2, (1080, 360))])
+def test_stage3_lean_option_is_bit_identical(mode, batch, shape):
     """VST_OPT_STAGE3_LEAN (vstnet.h): the 256-channel convs of bf16x3 as half-CU workgroups (4 waves, 8 x 16 tiles) give the
-    same bits as the 8-wave form (same MFMA order per accumulator) - full size, ragged tiles, a frame smaller than a tile."""
+    same bits as the 8-wave form (same MFMA order per accumulator) - full size, ragged tiles, a frame smaller than a tile, an
+    artistic batch (several images per launch), a tall batch whose quarter-resolution height (270) is not a multiple of 8."""
     from models.cWCT import cWCT
     from vstnet_amd import _lib
-    net, sd, sp = make_net("photo", "bf16x3")
+    net, sd, sp = make_net(mode, "bf16x3")
     cw = cWCT(precision="bf16x3")
     h, w = shape
-    xc, xs = synthetic_frames(1, h, w, seed=0).cuda(), synthetic_frames(1, h, w, seed=1).cuda()
+    xc, xs = synthetic_frames(batch, h, w, seed=0).cuda(), synthetic_frames(batch, h, w, seed=1).cuda()
     res = []
     assert _lib.get_option(_lib.OPT_STAGE3_LEAN) in (0, 1)
     before = _lib.get_option(_lib.OPT_STAGE3_LEAN)
