@@ -134,7 +134,10 @@ struct ConvCfg {
     static constexpr int CC = CIN >= 32 ? 32 : CIN;      // input channels staged per chunk
     static constexpr int NCHUNK = CIN / CC;
     static constexpr int CIG = CC >= 8 ? CC / 8 : 1;     // 8-channel groups per chunk
-    static constexpr int KS = CIN >= 32 ? 9 : (CIN == 16 ? 5 : 2);   // 32-deep k steps per chunk
+#ifndef VST_ABLATE_KS16
+#define VST_ABLATE_KS16 5            // (timing-only builds: fewer k-steps for the 16-channel inputs = what folding the horizontal tap into N would issue)
+#endif
+    static constexpr int KS = CIN >= 32 ? 9 : (CIN == 16 ? VST_ABLATE_KS16 : 2);   // 32-deep k steps per chunk
     static constexpr int A_PLANE = CIN == 4 ? NSLOT * 8 : CIG * NSLOT * 16;
     static constexpr int B_PLANE = KS * 4 * NT * 16;
     static constexpr int LDS_BYTES = 2 * A_PLANE + 2 * B_PLANE;
